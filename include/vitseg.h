@@ -1,0 +1,139 @@
+/*
+ * vitseg.h -- C ABI of libvitseg.so: the MI355X (gfx950) implementation of the
+ * ViT-encoder + conv-segmentation-head hot path of mtumalan/VisionTransformer.
+ *
+ * The reference has no FFI of its own (it is pure Python on PyTorch); its
+ * boundary for this path is the Python class surface
+ *     ViTSegmentationModel.__init__/forward      /root/reference/model/CE/classes.py:221-262
+ *     LightningViTModel.training_step/...        /root/reference/model/CE/classes.py:264-297
+ *     inference post-processing                  /root/reference/model/CE/testViTModel.py:119-126
+ * Every entry point below replaces the arithmetic behind one of those calls;
+ * the Python mirror of the class surface lives in visiontransformer_amd/ and
+ * binds these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - plain C types only; no exceptions cross the boundary.
+ *  - every function returns 0 on success or a negative VITSEG_E* code; a
+ *    human-readable message is kept per thread (vitseg_last_error()).
+ *  - the caller owns ALL device memory (parameters, activations, workspace).
+ *    No hipMalloc/hipFree/synchronise happens inside a call; all work is
+ *    enqueued on the `stream` argument (a hipStream_t passed as void*).
+ *  - parameters live in ONE fp32 arena whose layout this library defines
+ *    (vitseg_param_offset); data pointers must be 16-byte aligned.
+ *  - token rows inside the workspace are laid out "patches first":
+ *    row b*Np + t for patch token t of image b, row B*Np + b for the CLS token.
+ */
+#ifndef VITSEG_H
+#define VITSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITSEG_VERSION 100 /* 0.1.0 */
+
+enum vitseg_status {
+    VITSEG_OK = 0,
+    VITSEG_EINVAL = -1,     /* bad argument / null pointer / misalignment */
+    VITSEG_ESHAPE = -2,     /* shape the reference would reject (ValueError) or this build cannot run */
+    VITSEG_EWORKSPACE = -3, /* workspace too small */
+    VITSEG_EHIP = -4        /* a HIP runtime call / launch failed */
+};
+
+/* Constructor arguments of ViTSegmentationModel (classes.py:222) + the values
+ * the reference hard-codes in its ViTConfig (classes.py:224-235). */
+typedef struct vitseg_config {
+    int32_t num_classes;       /* C */
+    int32_t patch_size;        /* P  (multiple of 4) */
+    int32_t hidden_size;       /* D  (multiple of 4) */
+    int32_t num_layers;        /* L */
+    int32_t num_heads;         /* A;  D / A must be 64 in this build */
+    int32_t image_size;        /* S  (reference: 224) */
+    int32_t intermediate_size; /* I  (reference: 3072) */
+    int32_t num_channels;      /* 3 */
+    float layer_norm_eps;      /* 1e-12, configuration_vit.py:58 */
+} vitseg_config;
+
+/* Parameter tensors, in arena order.  Per-layer tensors take a layer index. */
+enum vitseg_tensor {
+    VITSEG_T_CLS = 0,   /* [D]            backbone.embeddings.cls_token */
+    VITSEG_T_POS,       /* [N, D]         backbone.embeddings.position_embeddings (row 0 = CLS) */
+    VITSEG_T_PATCH_W,   /* [D, 3*P*P]     ...patch_embeddings.projection.weight, K order (c,py,px) */
+    VITSEG_T_PATCH_B,   /* [D] */
+    VITSEG_T_LN1_W,     /* [D]            layers.i.layernorm_before */
+    VITSEG_T_LN1_B,
+    VITSEG_T_WQKV,      /* [3D, D]        rows: q_proj, k_proj, v_proj weights stacked */
+    VITSEG_T_BQKV,      /* [3D] */
+    VITSEG_T_WO,        /* [D, D]         attention.o_proj */
+    VITSEG_T_BO,
+    VITSEG_T_LN2_W,     /* [D]            layernorm_after */
+    VITSEG_T_LN2_B,
+    VITSEG_T_W1,        /* [I, D]         mlp.fc1 */
+    VITSEG_T_B1,
+    VITSEG_T_W2,        /* [D, I]         mlp.fc2 */
+    VITSEG_T_B2,
+    VITSEG_T_LNF_W,     /* [D]            backbone.layernorm */
+    VITSEG_T_LNF_B,
+    VITSEG_T_HEAD0_W,   /* [256, 3, 3, D] seg_head.0.weight permuted (out, ky, kx, in) */
+    VITSEG_T_HEAD0_B,   /* [256] */
+    VITSEG_T_HEAD2_W,   /* [C, 256]       seg_head.2.weight */
+    VITSEG_T_HEAD2_B,   /* [C] */
+    VITSEG_T_COUNT
+};
+
+/* Precision of the encoder arithmetic. */
+enum vitseg_precision {
+    VITSEG_F32 = 0, /* fp32 storage, fp32-input MFMA (exact fmaf chains): the parity path */
+    VITSEG_BF16 = 1 /* bf16 operands / fp32 accumulate MFMA, fp32 residual stream and softmax */
+};
+
+/* Workspace buffers whose contents are defined after vitseg_forward returns
+ * (used by the parity tests to read intermediate stages). */
+enum vitseg_buffer {
+    VITSEG_BUF_TOKENS = 0, /* fp32 [B*Np + B, D] residual stream after the last layer */
+    VITSEG_BUF_LOWRES,     /* fp32 [B, C, g, g]  low-resolution logits (seg_head output) */
+    VITSEG_BUF_COUNT
+};
+
+int vitseg_version(void);
+const char* vitseg_last_error(void);
+
+/* ---- parameter arena (replaces nn.Module parameter storage, classes.py:222-244) ---- */
+int vitseg_param_count(const vitseg_config* cfg, size_t* n_floats);
+int vitseg_param_offset(const vitseg_config* cfg, int tensor, int layer, size_t* offset_floats, size_t* numel);
+
+/* fp32 arena -> bf16 shadow arena (same offsets, 2 bytes/elt); needed before a VITSEG_BF16 forward. */
+int vitseg_cast_params_bf16(const float* params, void* params_bf16, size_t n_floats, void* stream);
+
+/* ---- forward (replaces ViTSegmentationModel.forward, classes.py:246-262, and the
+ *      sigmoid->argmax post-processing of testViTModel.py:122-126) ---- */
+int vitseg_query_workspace(const vitseg_config* cfg, int batch, int precision, size_t* bytes);
+int vitseg_workspace_offset(const vitseg_config* cfg, int batch, int precision, int buffer, size_t* offset_bytes,
+                            size_t* bytes);
+
+/* x: fp32 NCHW [batch, 3, S, S] on device.  logits (fp32 [batch, C, S, S]) and mask
+ * (uint8 [batch, S, S], = argmax_c sigmoid(logits), first maximal index) may each be NULL.
+ * params_bf16 is only read when precision == VITSEG_BF16. */
+int vitseg_forward(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x, int batch,
+                   int precision, float* logits, uint8_t* mask, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- single-operator entry points (same kernels the forward uses; exported so each
+ *      stage can be checked against the oracle in isolation) ---- */
+int vitseg_op_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps,
+                            void* stream);
+/* C[M,N] = epi(A[M,K] . W[N,K]^T + bias); epi: 0 none, 1 erf-GELU, 2 + R[M,N] (R may alias C), 3 ReLU */
+int vitseg_op_linear_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
+                         int K, int epilogue, void* stream);
+/* qkv: [B*Np + B, 3*A*64] rows as in the workspace; ctx: [B*Np + B, A*64] */
+int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream);
+/* lowres fp32 [B, C, g, g] -> logits fp32 [B, C, S, S] and/or mask uint8 [B, S, S] */
+int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask, int batch, int C, int g, int S,
+                              void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITSEG_H */

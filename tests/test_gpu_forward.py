@@ -1,0 +1,84 @@
+"""GPU (-m gpu): the whole hot path through ViTSegmentationModel -> libvitseg.so against
+(1) the committed golden vectors of the real reference class and (2) the oracle on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitseg_oracle as O
+from util import CASES, Golden
+from visiontransformer_amd import _lib, synth
+from visiontransformer_amd.config import ViTSegConfig
+from visiontransformer_amd.model import ViTSegmentationModel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_LOGITS = 1e-3  # BASELINE.json north_star: "logits within 1e-3 fp32"
+
+
+def build(g: Golden, precision="fp32"):
+    c = g.cfg
+    m = ViTSegmentationModel(c.num_classes, c.patch_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
+                             image_size=c.image_size, intermediate_size=c.intermediate_size, precision=precision,
+                             device=DEV).eval()
+    m.load_state_dict(g.state_dict())
+    return m
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_golden(name):
+    g = Golden(name)
+    m = build(g)
+    x = g.images().to(DEV)
+    with torch.no_grad():
+        mask, logits = m.predict_mask(x, return_logits=True)
+    torch.cuda.synchronize()
+    scale = max(1.0, g.head_gain)  # the saturating case multiplies the logits by head_gain
+    err, _ = g.max_abs_err("logits", logits)
+    assert err <= TOL_LOGITS * scale, err
+    assert g.checksum_rel_err("logits", logits) < 1e-4
+    low = m.debug_buffer(g.batch, _lib.BUF_LOWRES).view(g.batch, g.cfg.num_classes, g.cfg.grid, g.cfg.grid)
+    assert np.abs(low.cpu().numpy() - g.z["lowres_logits.full"]).max() <= TOL_LOGITS * scale
+    # residual stream after the last layer vs the reference's last_hidden_state is checked through the final LN
+    # masks: identical to the reference wherever its decision is not numerically fragile
+    ref = g.mask()
+    got = mask.cpu().numpy()
+    bad = (got != ref) & ~g.fragile()
+    assert bad.sum() == 0, int(bad.sum())
+    assert (got != ref).mean() < 2e-3 if g.head_gain == 1.0 else True
+    # forward() (logits only) returns the same logits bit for bit
+    with torch.no_grad():
+        assert torch.equal(m(x), logits)
+
+
+def test_forward_matches_oracle_on_fresh_inputs():
+    """Seeded inputs that are NOT in the golden set, batch 3, compared with the oracle in fp64."""
+    cfg = ViTSegConfig(4, 16, 192, 3, 3, image_size=96)
+    sd_np = synth.make_state_dict(cfg, seed=21)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    x = torch.from_numpy(synth.make_images(cfg, 3, seed=5))
+    stages = {}
+    with torch.no_grad():
+        ref = O.forward(x.double(), {k: v.double() for k, v in sd.items()}, cfg, stages)
+    m = ViTSegmentationModel(4, 16, 192, 3, 3, image_size=96, device=DEV).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        got = m(x.to(DEV))
+    assert (got.cpu().double() - ref).abs().max().item() < 2e-5
+    tok = m.debug_buffer(3, _lib.BUF_TOKENS).view(-1, 192).cpu().double()
+    Np = cfg.num_patches
+    ref_tok = stages[f"layer_{cfg.num_hidden_layers - 1}"]
+    for b in range(3):
+        assert (tok[b * Np:(b + 1) * Np] - ref_tok[b, 1:]).abs().max().item() < 2e-5
+        assert (tok[3 * Np + b] - ref_tok[b, 0]).abs().max().item() < 2e-5
+
+
+def test_batch_invariance_and_determinism():
+    g = Golden("tiny16_224_c2")
+    m = build(g)
+    x = g.images().to(DEV)
+    with torch.no_grad():
+        a = m(x)
+        b = m(x)
+        c = m(x[1:3])
+    assert torch.equal(a, b)            # deterministic (no atomics on the path)
+    assert torch.equal(a[1:3], c)       # images are independent units: batch split == full batch (section 8e)

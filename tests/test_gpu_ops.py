@@ -1,0 +1,125 @@
+"""GPU (-m gpu): each HIP kernel, called through the C ABI, against the oracle on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitseg_oracle as O
+from visiontransformer_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+@pytest.mark.parametrize("rows,D", [(7, 192), (1025, 768), (33, 1024), (5, 2048), (9, 512)])
+def test_layernorm(rows, D):
+    x, w, b = _rand(rows, D, seed=1, scale=3.0) + 0.5, _rand(D, seed=2) + 1.0, _rand(D, seed=3)
+    ref = O.layer_norm(x.double(), w.double(), b.double(), 1e-12)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y = torch.empty_like(xd)
+    _lib.check(_lib.lib().vitseg_op_layernorm_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), rows, D,
+                                                  1e-12, _stream()))
+    assert (y.cpu().double() - ref).abs().max().item() < 5e-6  # tolerance: fp32 rounding of O(1) outputs
+
+
+@pytest.mark.parametrize("M,N,K,epi", [
+    (128, 128, 32, 0), (257, 192, 64, 0), (788, 576, 192, 0), (300, 768, 768, 1), (1025, 768, 3072, 2),
+    (130, 3072, 768, 1), (64, 256, 6912, 3), (33, 100, 48, 0), (2050, 2304, 768, 0)])
+def test_linear_epilogues(M, N, K, epi):
+    A, W, bias = _rand(M, K, seed=M), _rand(N, K, seed=N + 1, scale=0.05), _rand(N, seed=7, scale=0.1)
+    R = _rand(M, N, seed=11)
+    acc = A.double() @ W.double().T + bias.double()
+    if epi == 1:
+        ref = O.gelu_erf(acc)
+    elif epi == 2:
+        ref = R.double() + acc
+    elif epi == 3:
+        ref = torch.relu(acc)
+    else:
+        ref = acc
+    Ad, Wd, bd, Rd = A.to(DEV), W.to(DEV), bias.to(DEV), R.to(DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    if epi == 2:  # in-place residual, as the forward uses it
+        C.copy_(Rd)
+        Rp = C.data_ptr()
+    else:
+        Rp = None
+    _lib.check(_lib.lib().vitseg_op_linear_f32(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), Rp, C.data_ptr(), M, N, K,
+                                               epi, _stream()))
+    err = (C.cpu().double() - ref).abs().max().item()
+    # fp32 fmaf chain over K terms of magnitude ~|a||w|: error ~ 1e-7 * sum|a w|
+    bound = 4e-7 * (A.abs().double() @ W.abs().double().T).max().item() + 1e-6
+    assert err < bound, (err, bound)
+
+
+def test_linear_matches_fp32_fmaf_semantics_exactly_small():
+    """A = I (asymmetric W) must come out exactly: catches row/col swaps in the MFMA C layout."""
+    M = N = K = 128
+    A = torch.eye(M)
+    W = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 1024.0
+    C = torch.empty(M, N, device=DEV)
+    Ad, Wd = A.to(DEV), W.to(DEV)  # keep the device tensors alive across the call
+    _lib.check(_lib.lib().vitseg_op_linear_f32(Ad.data_ptr(), Wd.data_ptr(), None, None, C.data_ptr(),
+                                               M, N, K, 0, _stream()))
+    assert torch.equal(C.cpu(), W.T.contiguous())
+
+
+@pytest.mark.parametrize("B,Np,A", [(2, 196, 3), (1, 1024, 2), (3, 784, 1), (1, 64, 1), (2, 128, 12), (1, 200, 2)])
+def test_attention(B, Np, A):
+    D = 64 * A
+    Mt = B * Np + B
+    qkv = _rand(Mt, 3 * D, seed=Np + A, scale=1.5)
+    # spike one key against one query so the running max jumps mid-sequence (online-softmax rescale path)
+    qkv[Np // 2, :64] *= 6.0
+    qkv[(Np * 3) // 4, D:D + 64] = qkv[Np // 2, :64]
+
+    def rows(b):  # oracle order: CLS first
+        return torch.cat([torch.tensor([B * Np + b]), torch.arange(b * Np, (b + 1) * Np)])
+
+    ref = torch.empty(Mt, D, dtype=torch.float64)
+    x64 = qkv.double()
+    for b in range(B):
+        r = rows(b)
+        q, k, v = [x64[r][:, i * D:(i + 1) * D].reshape(Np + 1, A, 64).transpose(0, 1) for i in range(3)]
+        s = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+        ref[r] = (s @ v).transpose(0, 1).reshape(Np + 1, D)
+    qd = qkv.to(DEV)
+    ctx = torch.full((Mt, D), float("nan"), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_attention_f32(qd.data_ptr(), ctx.data_ptr(), B, Np, A, _stream()))
+    err = (ctx.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5, err  # fp32 exp2/softmax on O(1) values
+
+
+@pytest.mark.parametrize("B,C,g,S", [(2, 2, 14, 224), (1, 17, 14, 224), (1, 2, 32, 512), (1, 3, 28, 224), (1, 1, 8, 64)])
+def test_upsample_sigmoid_argmax_bit_exact(B, C, g, S):
+    z = _rand(B, C, g, g, seed=g + C, scale=2.0)
+    if C >= 3:
+        z[:, 1] += 18.0  # saturate two classes: sigmoid -> 1.0f for both, first index must win
+        z[:, 2] += 19.0
+    ref_logits = O.upsample_bilinear(z, (S, S))
+    assert torch.equal(ref_logits, torch.nn.functional.interpolate(z, size=(S, S), mode="bilinear", align_corners=False))
+    ref_mask = O.predict_mask(ref_logits)
+    zd = z.to(DEV)
+    logits = torch.empty(B, C, S, S, device=DEV)
+    mask = torch.empty(B, S, S, dtype=torch.uint8, device=DEV)
+    _lib.check(_lib.lib().vitseg_op_upsample_argmax(zd.data_ptr(), logits.data_ptr(), mask.data_ptr(), B, C, g, S,
+                                                    _stream()))
+    assert torch.equal(logits.cpu(), ref_logits)  # bit-exact: same fma placement as ATen's CPU kernel
+    mism = (mask.cpu().long() != ref_mask)
+    # sigmoid is 1/(1+exp(-x)) on both sides; only a 1-ulp expf difference between libm and ocml can move a tie
+    sg = ref_logits.sigmoid().sort(dim=1, descending=True).values
+    near_tie = (sg[:, 0] - sg[:, 1]).abs() <= 2 * torch.finfo(torch.float32).eps if C > 1 else torch.zeros_like(mism)
+    assert (mism & ~near_tie).sum().item() == 0
+    assert mism.sum().item() <= 1e-4 * mism.numel()
+    # mask-only call (logits pointer NULL) gives the same mask
+    mask2 = torch.empty_like(mask)
+    _lib.check(_lib.lib().vitseg_op_upsample_argmax(zd.data_ptr(), None, mask2.data_ptr(), B, C, g, S, _stream()))
+    assert torch.equal(mask, mask2)

@@ -1,0 +1,107 @@
+"""ctypes binding of csrc/libvitseg.so (C ABI: include/vitseg.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, importing
+this module's `lib()` raises -- the product path must never silently run elsewhere.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .config import ViTSegConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvitseg.so")
+
+OK, EINVAL, ESHAPE, EWORKSPACE, EHIP = 0, -1, -2, -3, -4
+F32, BF16 = 0, 1
+BUF_TOKENS, BUF_LOWRES = 0, 1
+
+# enum vitseg_tensor
+(T_CLS, T_POS, T_PATCH_W, T_PATCH_B, T_LN1_W, T_LN1_B, T_WQKV, T_BQKV, T_WO, T_BO, T_LN2_W, T_LN2_B,
+ T_W1, T_B1, T_W2, T_B2, T_LNF_W, T_LNF_B, T_HEAD0_W, T_HEAD0_B, T_HEAD2_W, T_HEAD2_B, T_COUNT) = range(23)
+
+EXPORTS = [
+    "vitseg_version", "vitseg_last_error", "vitseg_param_count", "vitseg_param_offset", "vitseg_cast_params_bf16",
+    "vitseg_query_workspace", "vitseg_workspace_offset", "vitseg_forward", "vitseg_op_layernorm_f32",
+    "vitseg_op_linear_f32", "vitseg_op_attention_f32", "vitseg_op_upsample_argmax",
+]
+
+
+class CConfig(C.Structure):
+    _fields_ = [("num_classes", C.c_int32), ("patch_size", C.c_int32), ("hidden_size", C.c_int32),
+                ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("image_size", C.c_int32),
+                ("intermediate_size", C.c_int32), ("num_channels", C.c_int32), ("layer_norm_eps", C.c_float)]
+
+    @classmethod
+    def from_config(cls, cfg: ViTSegConfig) -> "CConfig":
+        return cls(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+                   cfg.num_attention_heads, cfg.image_size, cfg.intermediate_size, cfg.num_channels,
+                   cfg.layer_norm_eps)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m visiontransformer_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+        l = C.CDLL(LIB_PATH)
+        vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+        pcfg, psz = C.POINTER(CConfig), C.POINTER(C.c_size_t)
+        l.vitseg_version.restype = i32
+        l.vitseg_last_error.restype = C.c_char_p
+        l.vitseg_param_count.argtypes = [pcfg, psz]
+        l.vitseg_param_offset.argtypes = [pcfg, i32, i32, psz, psz]
+        l.vitseg_cast_params_bf16.argtypes = [vp, vp, sz, vp]
+        l.vitseg_query_workspace.argtypes = [pcfg, i32, i32, psz]
+        l.vitseg_workspace_offset.argtypes = [pcfg, i32, i32, i32, psz, psz]
+        l.vitseg_forward.argtypes = [pcfg, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]
+        l.vitseg_op_layernorm_f32.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp]
+        l.vitseg_op_linear_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        l.vitseg_op_attention_f32.argtypes = [vp, vp, i32, i32, i32, vp]
+        l.vitseg_op_upsample_argmax.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+        for name in EXPORTS:
+            getattr(l, name)  # raises AttributeError if the build is stale
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> None:
+    """Maps C status codes to the exception types the reference raises
+    (ValueError for shapes the reference rejects, modeling_vit.py:63-68,152-156)."""
+    if rc == OK:
+        return
+    msg = lib().vitseg_last_error().decode(errors="replace")
+    if rc == ESHAPE:
+        raise ValueError(msg)
+    raise RuntimeError(f"libvitseg error {rc}: {msg}")
+
+
+def param_count(cfg: ViTSegConfig) -> int:
+    n = C.c_size_t()
+    check(lib().vitseg_param_count(C.byref(CConfig.from_config(cfg)), C.byref(n)))
+    return n.value
+
+
+def param_offset(cfg: ViTSegConfig, tensor: int, layer: int = 0):
+    off, n = C.c_size_t(), C.c_size_t()
+    check(lib().vitseg_param_offset(C.byref(CConfig.from_config(cfg)), tensor, layer, C.byref(off), C.byref(n)))
+    return off.value, n.value
+
+
+def query_workspace(cfg: ViTSegConfig, batch: int, precision: int) -> int:
+    n = C.c_size_t()
+    check(lib().vitseg_query_workspace(C.byref(CConfig.from_config(cfg)), batch, precision, C.byref(n)))
+    return n.value
+
+
+def workspace_offset(cfg: ViTSegConfig, batch: int, precision: int, buffer: int):
+    off, n = C.c_size_t(), C.c_size_t()
+    check(lib().vitseg_workspace_offset(C.byref(CConfig.from_config(cfg)), batch, precision, buffer,
+                                        C.byref(off), C.byref(n)))
+    return off.value, n.value

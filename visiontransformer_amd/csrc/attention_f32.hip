@@ -1,0 +1,286 @@
+// Multi-head self-attention core in fp32:  ctx = softmax(q k^T * hd^-0.5) v
+//
+// Replaces eager_attention_forward / torch SDPA behind ViTAttention
+// (transformers/models/vit/modeling_vit.py:164-189, called from :207-238); 7-23 % of the
+// reference's CPU profile.  No mask, eval mode, fp32 softmax.
+//
+// Flash-style (the [N,N] score matrix is never materialised), on the fp32-input matrix
+// cores (v_mfma_f32_32x32x2_f32, exact fmaf chains; bound: 157.3 TFLOP/s fp32 matrix peak).
+//
+// Row layout ("patches first"): q/k/v of patch token t of image b live in row b*Np + t of
+// qkv[.., 3D]; the CLS token of image b in row B*Np + b.  That keeps the Np patch keys of an
+// image a whole number of 64-key tiles at 512x512 (Np = 1024) -- the CLS key is folded in as
+// the INITIAL state of the online softmax (m = s_cls, l = 1, O = v_cls), so the key loop has
+// no ragged tail and no mask.  The B*A CLS *queries* are one extra row each and run in a
+// small second kernel.
+//
+// Per block: 128 queries of one (image, head); 4 waves x 32 queries.  Scores are computed
+// transposed, S^T = K . Q^T (A operand = K tile from LDS, B operand = Q held in registers), so a
+// lane owns ONE query column: row max / row sum / rescale are lane-local plus one lane^32
+// exchange, and the exponentiated S^T accumulator registers are directly the B operand of
+// O^T = V^T . P^T (register s <-> key (s&3) + 8(s>>2) + 4(lane>>5) on both sides).
+// head_dim is fixed at 64 (every configuration of the reference: 192/3, 512/8, 768/12, 1024/16).
+#include "kernels.hpp"
+
+namespace vitseg {
+namespace {
+
+constexpr int HD = 64;      // head dim
+constexpr int QB = 128;     // queries per block
+constexpr int KB = 64;      // keys per LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+template <bool RAGGED>
+__global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                          int B, int Np, int A) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][KB * HD];  // [buffer][K|V][key*64 + d], 64 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int D = A * HD, ld = 3 * D;
+    const size_t row0 = (size_t)b * Np;           // first patch row of this image
+    const size_t cls_row = (size_t)B * Np + b;    // CLS row of this image
+    const float* qbase = qkv + head * HD;
+    const float* kbase = qkv + D + head * HD;
+    const float* vbase = qkv + 2 * D + head * HD;
+
+    // ---- this lane's query row, pre-scaled by hd^-0.5 * log2(e) (scores live in log2 units) ----
+    const int q_local = blockIdx.x * QB + wave * 32 + li;
+    const bool q_valid = q_local < Np;
+    const size_t q_row = row0 + (q_valid ? q_local : Np - 1);
+    const float qscale = 0.125f * LOG2E;
+    float qreg[32];  // element 4c+e = Q[8c + 4 lh + e]
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4 t = *(const f32x4*)(qbase + q_row * ld + 8 * c + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qreg[4 * c + e] = t[e] * qscale;
+    }
+
+    // ---- online-softmax state, initialised with the CLS key ----
+    float m_run, l_run;
+    f32x16 o[2];
+    {
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 t = *(const f32x4*)(kbase + cls_row * ld + 8 * c + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part = fmaf(qreg[4 * c + e], t[e], part);
+        }
+        m_run = part + __shfl_xor(part, 32, 64);
+        l_run = lh == 0 ? 1.f : 0.f;  // halves are summed at the end
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 t = *(const f32x4*)(vbase + cls_row * ld + dt * 32 + 8 * g4 + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[dt][4 * g4 + e] = t[e];
+            }
+    }
+
+    // ---- K/V tile staging: thread owns 16-B chunk lc of keys lr + 16 i ----
+    const int lc = tid & 15, lr = tid >> 4;
+    f32x4 rk[4], rv[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int key = kt * KB + lr + 16 * i;
+            if (RAGGED) key = min(key, Np - 1);  // duplicates are masked below
+            const size_t off = (row0 + key) * ld + 4 * lc;
+            rk[i] = *(const f32x4*)(kbase + off);
+            rv[i] = *(const f32x4*)(vbase + off);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = lr + 16 * i;
+            *(f32x4*)&lds[buf][0][key * HD + ((lc ^ (key & 15)) << 2)] = rk[i];  // K: chunk ^ (key & 15)
+            *(f32x4*)&lds[buf][1][key * HD + (lc << 2)] = rv[i];                 // V: linear
+        }
+    };
+
+    const int nkt = (Np + KB - 1) / KB;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+        const float* Ks = lds[buf][0];
+        const float* Vs = lds[buf][1];
+
+        // S^T[key][query] for 2 blocks of 32 keys
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+            const int key = kb * 32 + li;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 kf = *(const f32x4*)&Ks[key * HD + (((2 * c + lh) ^ (key & 15)) << 2)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    st[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[4 * c + e], st[kb], 0, 0, 0);
+            }
+        }
+        if (RAGGED) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * KB + kb * 32 + kappa(r, lh) >= Np) st[kb][r] = -INFINITY;
+        }
+        // online softmax for this lane's query
+        float mx = st[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+                st[kb][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // O^T[d][query] += V^T[d][key] . P^T[key][query]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int key = kb * 32 + kappa(s, lh);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const float vf = Vs[key * HD + dt * 32 + li];
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, st[kb][s], o[dt], 0, 0, 0);
+                }
+            }
+
+        if (kt + 1 < nkt) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds d = dt*32 + 8 g4 + 4 lh + e of its query ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_valid) {
+        float* out = ctx + q_row * (size_t)D + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = o[dt][4 * g4 + e] * inv;
+                *(f32x4*)(out + dt * 32 + 8 * g4 + 4 * lh) = t;
+            }
+    }
+}
+
+// The B*A CLS queries: one block per (head, image); plain VALU (1 x N x 64 per block).
+__global__ __launch_bounds__(256) void attn_cls_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                           int B, int Np, int A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // scores[N] then reduce scratch
+    const int N = Np + 1;
+    float* sc = sm;
+    float* red = sm + ((N + 63) & ~63);  // 16 groups x 64 floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int D = A * HD, ld = 3 * D;
+    const size_t row0 = (size_t)b * Np, cls_row = (size_t)B * Np + b;
+    const float* qp = qkv + cls_row * ld + head * HD;
+    const float* kbase = qkv + D + head * HD;
+    const float* vbase = qkv + 2 * D + head * HD;
+    const int sub = lane & 15, grp = lane >> 4;  // 16 lanes x 16 B cover one 64-float row
+
+    f32x4 q4 = *(const f32x4*)(qp + 4 * sub);
+    const float qs = 0.125f * LOG2E;
+    for (int e = 0; e < 4; ++e) q4[e] *= qs;
+    for (int base = wave * 4; base < N; base += 16) {
+        const int key = base + grp;
+        float part = 0.f;
+        if (key < N) {
+            const size_t row = key < Np ? row0 + key : cls_row;
+            const f32x4 k4 = *(const f32x4*)(kbase + row * ld + 4 * sub);
+            part = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        part += __shfl_xor(part, 8, 64);
+        if (sub == 0 && key < N) sc[key] = part;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < N; i += 256) {
+        const float pv = __builtin_amdgcn_exp2f(sc[i] - mx);
+        sc[i] = pv;
+        sum += pv;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    // out[d] = sum_key p[key] V[key][d]: thread = (key group kg of 16, 4-float chunk sub)
+    const int kg = tid >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int key = kg; key < N; key += 16) {
+        const size_t row = key < Np ? row0 + key : cls_row;
+        const f32x4 v4 = *(const f32x4*)(vbase + row * ld + 4 * sub);
+        const float pv = sc[key];
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(pv, v4[e], acc[e]);
+    }
+    *(f32x4*)&red[kg * 64 + 4 * sub] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+        for (int g = 0; g < 16; ++g) s += red[g * 64 + tid];
+        ctx[cls_row * (size_t)D + head * HD + tid] = s * inv;
+    }
+}
+
+}  // namespace
+
+int launch_attention_f32(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s) {
+    VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_f32: bad arguments");
+    const dim3 grid((Np + QB - 1) / QB, A, B);
+    if (Np % QB == 0)
+        hipLaunchKernelGGL(attn_f32_kernel<false>, grid, dim3(256), 0, s, qkv, ctx, B, Np, A);
+    else
+        hipLaunchKernelGGL(attn_f32_kernel<true>, grid, dim3(256), 0, s, qkv, ctx, B, Np, A);
+    VITSEG_LAUNCH_CHECK("attn_f32");
+    const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 16 * 64) * sizeof(float);
+    VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_f32: sequence too long for the CLS kernel");
+    hipLaunchKernelGGL(attn_cls_f32_kernel, dim3(A, B), dim3(256), smem, s, qkv, ctx, B, Np, A);
+    VITSEG_LAUNCH_CHECK("attn_cls_f32");
+    return VITSEG_OK;
+}
+
+}  // namespace vitseg

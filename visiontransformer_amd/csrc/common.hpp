@@ -1,0 +1,66 @@
+// Shared device/host helpers for libvitseg (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vitseg.h"
+
+namespace vitseg {
+
+constexpr int WAVE = 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+// thread-local error message (vitseg_last_error)
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define VITSEG_CHECK_ARG(cond, code, ...) \
+    do {                                  \
+        if (!(cond)) {                    \
+            ::vitseg::set_error(__VA_ARGS__); \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+#define VITSEG_LAUNCH_CHECK(what)                               \
+    do {                                                        \
+        hipError_t e__ = hipGetLastError();                     \
+        if (e__ != hipSuccess) return ::vitseg::hip_fail(e__, what); \
+    } while (0)
+
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give each
+// XCD a contiguous run of the logical tile list so neighbouring tiles (which share
+// operand panels) hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact (erf) GELU, activations.py:78-83
+__device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    // round-to-nearest-even; NaN stays NaN (quiet)
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+}  // namespace vitseg

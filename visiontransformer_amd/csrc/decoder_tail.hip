@@ -1,0 +1,117 @@
+// Decoder tail: seg_head.2 (1x1 conv), bilinear upsample, sigmoid -> argmax mask.
+#include "kernels.hpp"
+
+namespace vitseg {
+namespace {
+
+constexpr int MID = 256;  // seg_head.0 output channels, model/CE/classes.py:241
+
+// seg_head.2 = Conv2d(256, C, 1) (model/CE/classes.py:243): Z[b, c, y, x] = F[b*Np + t, :] . W2[c, :] + b2[c].
+// One wave per pixel row of F (256 floats = 64 lanes x 16 B); tiny (2*Np*256*C FLOP/image).
+__global__ __launch_bounds__(256) void head1x1_kernel(const float* __restrict__ F, const float* __restrict__ W2,
+                                                      const float* __restrict__ b2, float* __restrict__ Z, int B,
+                                                      int Np, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * Np) return;
+    const f32x4 f = ((const f32x4*)(F + (size_t)row * MID))[lane];
+    const int b = row / Np, t = row - b * Np;
+    for (int c = 0; c < C; ++c) {
+        const f32x4 w = ((const f32x4*)(W2 + (size_t)c * MID))[lane];
+        float s = (f[0] * w[0] + f[1] * w[1]) + (f[2] * w[2] + f[3] * w[3]);
+        s = wave_sum(s);
+        if (lane == 0) Z[((size_t)b * C + c) * Np + t] = s + b2[c];
+    }
+}
+
+// F.interpolate(out, size=x.shape[2:], mode='bilinear', align_corners=False)
+// (model/CE/classes.py:260) fused with the scripts' post-processing
+// `logits.sigmoid()` -> `argmax(dim=class)` (model/CE/testViTModel.py:122-126).
+//
+// Bit-exact restatement of ATen's CPU kernel as built for x86+FMA (see
+// oracle/vitseg_oracle.py:upsample_bilinear): taps src = max(scale*(d+0.5)-0.5, 0),
+//   row = fma(a, wx0, b*wx1);  out = fma(row_top, wy0, row_bot*wy1).
+// Explicit __f*_rn intrinsics keep hipcc from re-contracting the expression.
+// Bound: HBM writes (C*S*S*4 B logits and/or S*S B mask per image); the low-res input
+// (C*g*g*4 B per image) stays in L2.  Thread = 4 consecutive x of one output row.
+__device__ __forceinline__ void taps(int d, float scale, int n_in, int& i0, int& i1, float& w0, float& w1) {
+    float src = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)d, 0.5f)), 0.5f);
+    src = src < 0.f ? 0.f : src;
+    i0 = min((int)floorf(src), n_in - 1);
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    w1 = fminf(fmaxf(__fsub_rn(src, (float)i0), 0.f), 1.f);
+    w0 = __fsub_rn(1.f, w1);
+}
+
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ Z, float* __restrict__ logits,
+                                                       uint8_t* __restrict__ mask, int B, int C, int g, int S) {
+    const int quads = S >> 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * S * quads) return;
+    const int xq = (int)(idx % quads);
+    const int Y = (int)((idx / quads) % S);
+    const int b = (int)(idx / ((size_t)quads * S));
+    const float scale = (float)g / (float)S;
+    int y0, y1;
+    float wy0, wy1;
+    taps(Y, scale, g, y0, y1, wy0, wy1);
+    int x0[4], x1[4];
+    float wx0[4], wx1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) taps(4 * xq + e, scale, g, x0[e], x1[e], wx0[e], wx1[e]);
+
+    float best[4];
+    int arg[4];
+    for (int c = 0; c < C; ++c) {
+        const float* zt = Z + (((size_t)b * C + c) * g + y0) * g;
+        const float* zb = Z + (((size_t)b * C + c) * g + y1) * g;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float top = __fmaf_rn(zt[x0[e]], wx0[e], __fmul_rn(zt[x1[e]], wx1[e]));
+            const float bot = __fmaf_rn(zb[x0[e]], wx0[e], __fmul_rn(zb[x1[e]], wx1[e]));
+            v[e] = __fmaf_rn(top, wy0, __fmul_rn(bot, wy1));
+        }
+        if (logits) *(f32x4*)(logits + (((size_t)b * C + c) * S + Y) * S + 4 * xq) = v;
+        if (mask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // torch CPU sigmoid: 1 / (1 + exp(-x)), then argmax keeps the FIRST maximal class
+                const float sg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v[e])));
+                if (c == 0 || sg > best[e]) {
+                    best[e] = sg;
+                    arg[e] = c;
+                }
+            }
+        }
+    }
+    if (mask) {
+        uchar4 m4;
+        m4.x = (unsigned char)arg[0];
+        m4.y = (unsigned char)arg[1];
+        m4.z = (unsigned char)arg[2];
+        m4.w = (unsigned char)arg[3];
+        *(uchar4*)(mask + ((size_t)b * S + Y) * S + 4 * xq) = m4;
+    }
+}
+
+}  // namespace
+
+int launch_head1x1(const float* F, const float* W2, const float* b2, float* Z, int B, int Np, int C, hipStream_t s) {
+    VITSEG_CHECK_ARG(F && W2 && b2 && Z, VITSEG_EINVAL, "head1x1: null pointer");
+    hipLaunchKernelGGL(head1x1_kernel, dim3((B * Np + 3) / 4), dim3(256), 0, s, F, W2, b2, Z, B, Np, C);
+    VITSEG_LAUNCH_CHECK("head1x1");
+    return VITSEG_OK;
+}
+
+int launch_upsample(const float* Z, float* logits, uint8_t* mask, int B, int C, int g, int S, hipStream_t s) {
+    VITSEG_CHECK_ARG(Z && (logits || mask), VITSEG_EINVAL, "upsample: null pointer");
+    VITSEG_CHECK_ARG(S % 4 == 0 && C >= 1 && C <= 255, VITSEG_ESHAPE, "upsample: S %% 4 != 0 or C out of range");
+    const size_t n = (size_t)B * S * (S / 4);
+    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Z, logits, mask, B, C, g,
+                       S);
+    VITSEG_LAUNCH_CHECK("upsample");
+    return VITSEG_OK;
+}
+
+}  // namespace vitseg

@@ -1,0 +1,118 @@
+// HBM-bound row kernels: LayerNorm, CLS-row initialisation, fp32 -> bf16 cast.
+#include "kernels.hpp"
+
+namespace vitseg {
+namespace {
+
+// nn.LayerNorm(D, eps=1e-12) (transformers/models/vit/modeling_vit.py:261-262,274,281,348,385;
+// eps from configuration_vit.py:58).  Biased variance, two-pass in registers (a row of up to
+// 2048 floats lives in one wave's registers), row reductions by wavefront butterfly.
+// One wave per row, 4 rows per block.  Bound: HBM (read D*4 + write D*{4,2} bytes per row).
+template <typename OutT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, OutT* __restrict__ y, int rows,
+                                                        int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = D >> 2;
+    const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
+    f32x4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = xr[c];
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][e] -= mean;
+                q = fmaf(v[i][e], v[i][e], q);
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 wv = ((const f32x4*)w)[c];
+            const f32x4 bv = ((const f32x4*)b)[c];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * wv[e] + bv[e];
+            if constexpr (sizeof(OutT) == 4) {
+                ((f32x4*)(y + (size_t)row * D))[c] = o;
+            } else {
+                bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (short)f32_to_bf16(o[e]);
+                ((bf16x4*)(y + (size_t)row * D))[c] = h;
+            }
+        }
+    }
+}
+
+// embeddings: CLS rows  X[B*Np + b][:] = cls_token + position_embeddings[0]
+// (transformers/models/vit/modeling_vit.py:146-158)
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ X,
+                                int B, int Np, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    X[((size_t)B * Np + b) * D + d] = cls[d] + pos[d];
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        const f32x4 v = ((const f32x4*)src)[i];
+        bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (short)f32_to_bf16(v[e]);
+        ((bf16x4*)dst)[i] = h;
+    }
+}
+
+}  // namespace
+
+int launch_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int D, float eps,
+                     bool out_bf16, hipStream_t s) {
+    VITSEG_CHECK_ARG(x && w && b && y && rows > 0, VITSEG_EINVAL, "layernorm: bad arguments");
+    VITSEG_CHECK_ARG(D % 4 == 0 && D <= 2048, VITSEG_ESHAPE, "layernorm: D=%d must be a multiple of 4 and <= 2048", D);
+    const dim3 grid((rows + 3) / 4);
+    if (out_bf16)
+        hipLaunchKernelGGL(layernorm_kernel<unsigned short>, grid, dim3(256), 0, s, x, w, b, (unsigned short*)y, rows,
+                           D, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, w, b, (float*)y, rows, D, eps);
+    VITSEG_LAUNCH_CHECK("layernorm");
+    return VITSEG_OK;
+}
+
+int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int Np, int D, hipStream_t s) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, cls, pos, X, B, Np, D);
+    VITSEG_LAUNCH_CHECK("cls_rows");
+    return VITSEG_OK;
+}
+
+int launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
+    VITSEG_CHECK_ARG(n % 4 == 0, VITSEG_EINVAL, "cast_bf16: n %% 4");
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, s, src, (unsigned short*)dst, n4);
+    VITSEG_LAUNCH_CHECK("cast_bf16");
+    return VITSEG_OK;
+}
+
+}  // namespace vitseg

@@ -1,0 +1,324 @@
+// C ABI of libvitseg.so (include/vitseg.h): parameter-arena layout, workspace planning and
+// the forward orchestration of the ViT segmentation hot path
+// (ViTSegmentationModel.forward, /root/reference/model/CE/classes.py:246-262).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "kernels.hpp"
+
+namespace vitseg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return VITSEG_EHIP;
+}
+
+namespace {
+
+constexpr int MID = 256;
+constexpr size_t ALIGN_F = 64;  // arena tensors start on 256-byte boundaries
+
+inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Shape {
+    int C, P, D, L, A, S, I, Cin, g, Np, N, Kp;
+};
+
+int check_config(const vitseg_config* c, Shape* s) {
+    VITSEG_CHECK_ARG(c != nullptr, VITSEG_EINVAL, "config is null");
+    VITSEG_CHECK_ARG(c->num_classes >= 1 && c->num_classes <= 255, VITSEG_ESHAPE, "num_classes %d out of [1,255]",
+                     c->num_classes);
+    VITSEG_CHECK_ARG(c->patch_size >= 4 && c->patch_size % 4 == 0, VITSEG_ESHAPE,
+                     "patch_size %d must be a positive multiple of 4", c->patch_size);
+    VITSEG_CHECK_ARG(c->image_size > 0 && c->image_size % c->patch_size == 0, VITSEG_ESHAPE,
+                     "image_size %d is not a multiple of patch_size %d", c->image_size, c->patch_size);
+    VITSEG_CHECK_ARG(c->num_heads > 0 && c->hidden_size == 64 * c->num_heads, VITSEG_ESHAPE,
+                     "hidden_size %d / num_heads %d: this build needs head_dim 64", c->hidden_size, c->num_heads);
+    VITSEG_CHECK_ARG(c->hidden_size <= 2048, VITSEG_ESHAPE, "hidden_size %d > 2048", c->hidden_size);
+    VITSEG_CHECK_ARG(c->intermediate_size > 0 && c->intermediate_size % 4 == 0, VITSEG_ESHAPE,
+                     "intermediate_size %d must be a multiple of 4", c->intermediate_size);
+    VITSEG_CHECK_ARG(c->num_layers >= 1, VITSEG_ESHAPE, "num_layers %d", c->num_layers);
+    VITSEG_CHECK_ARG(c->num_channels == 3, VITSEG_ESHAPE, "num_channels %d (reference: 3)", c->num_channels);
+    s->C = c->num_classes;
+    s->P = c->patch_size;
+    s->D = c->hidden_size;
+    s->L = c->num_layers;
+    s->A = c->num_heads;
+    s->S = c->image_size;
+    s->I = c->intermediate_size;
+    s->Cin = c->num_channels;
+    s->g = s->S / s->P;
+    s->Np = s->g * s->g;
+    s->N = s->Np + 1;
+    s->Kp = s->Cin * s->P * s->P;
+    return VITSEG_OK;
+}
+
+size_t tensor_numel(const Shape& s, int t) {
+    const size_t D = s.D, I = s.I;
+    switch (t) {
+        case VITSEG_T_CLS: return D;
+        case VITSEG_T_POS: return (size_t)s.N * D;
+        case VITSEG_T_PATCH_W: return D * s.Kp;
+        case VITSEG_T_PATCH_B: return D;
+        case VITSEG_T_LN1_W: case VITSEG_T_LN1_B: case VITSEG_T_LN2_W: case VITSEG_T_LN2_B: return D;
+        case VITSEG_T_WQKV: return 3 * D * D;
+        case VITSEG_T_BQKV: return 3 * D;
+        case VITSEG_T_WO: return D * D;
+        case VITSEG_T_BO: return D;
+        case VITSEG_T_W1: return I * D;
+        case VITSEG_T_B1: return I;
+        case VITSEG_T_W2: return D * I;
+        case VITSEG_T_B2: return D;
+        case VITSEG_T_LNF_W: case VITSEG_T_LNF_B: return D;
+        case VITSEG_T_HEAD0_W: return (size_t)MID * 9 * D;
+        case VITSEG_T_HEAD0_B: return MID;
+        case VITSEG_T_HEAD2_W: return (size_t)s.C * MID;
+        case VITSEG_T_HEAD2_B: return s.C;
+    }
+    return 0;
+}
+
+inline bool per_layer(int t) { return t >= VITSEG_T_LN1_W && t <= VITSEG_T_B2; }
+
+// Arena order = forward order: embeddings, layer 0 .. L-1, final norm, head.
+struct Layout {
+    size_t pre[4];                   // CLS, POS, PATCH_W, PATCH_B
+    size_t layer0;                   // offset of layer 0
+    size_t layer_stride;             // floats per layer
+    size_t in_layer[VITSEG_T_B2 + 1];  // offset inside a layer, indexed by tensor id
+    size_t post[VITSEG_T_COUNT];     // LNF.., indexed by tensor id
+    size_t total;
+};
+
+Layout make_layout(const Shape& s) {
+    Layout l{};
+    size_t off = 0;
+    for (int t = VITSEG_T_CLS; t <= VITSEG_T_PATCH_B; ++t) {
+        l.pre[t] = off;
+        off += up(tensor_numel(s, t), ALIGN_F);
+    }
+    l.layer0 = off;
+    size_t lo = 0;
+    for (int t = VITSEG_T_LN1_W; t <= VITSEG_T_B2; ++t) {
+        l.in_layer[t] = lo;
+        lo += up(tensor_numel(s, t), ALIGN_F);
+    }
+    l.layer_stride = lo;
+    off += lo * s.L;
+    for (int t = VITSEG_T_LNF_W; t < VITSEG_T_COUNT; ++t) {
+        l.post[t] = off;
+        off += up(tensor_numel(s, t), ALIGN_F);
+    }
+    l.total = off;
+    return l;
+}
+
+inline size_t tensor_offset(const Layout& l, int t, int layer) {
+    if (t <= VITSEG_T_PATCH_B) return l.pre[t];
+    if (per_layer(t)) return l.layer0 + (size_t)layer * l.layer_stride + l.in_layer[t];
+    return l.post[t];
+}
+
+// ---- workspace plan -------------------------------------------------------------
+struct Plan {
+    size_t x, h, qkv, u, f, z, total;  // byte offsets
+    size_t Mt, Mp;                     // total token rows, patch rows
+};
+
+Plan make_plan(const Shape& s, int B, int precision) {
+    Plan p{};
+    p.Mp = (size_t)B * s.Np;
+    p.Mt = p.Mp + B;
+    const size_t act = precision == VITSEG_BF16 ? 2 : 4;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += up(bytes, 256);
+        return o;
+    };
+    p.x = take(p.Mt * s.D * 4);                       // fp32 residual stream
+    p.h = take(p.Mt * s.D * 4);                       // LN output / attention context (fp32 sized)
+    p.qkv = take(p.Mt * 3 * s.D * act);               // q | k | v
+    p.u = take(p.Mt * (size_t)s.I * act);             // MLP hidden
+    p.f = take(p.Mp * MID * 4);                       // seg_head.0 output (fp32)
+    p.z = take((size_t)B * s.C * s.Np * 4);           // low-res logits
+    p.total = off;
+    return p;
+}
+
+}  // namespace
+}  // namespace vitseg
+
+using namespace vitseg;
+
+extern "C" {
+
+int vitseg_version(void) { return VITSEG_VERSION; }
+const char* vitseg_last_error(void) { return g_err; }
+
+int vitseg_param_count(const vitseg_config* cfg, size_t* n_floats) {
+    Shape s;
+    if (int rc = check_config(cfg, &s)) return rc;
+    VITSEG_CHECK_ARG(n_floats, VITSEG_EINVAL, "n_floats is null");
+    *n_floats = make_layout(s).total;
+    return VITSEG_OK;
+}
+
+int vitseg_param_offset(const vitseg_config* cfg, int tensor, int layer, size_t* offset_floats, size_t* numel) {
+    Shape s;
+    if (int rc = check_config(cfg, &s)) return rc;
+    VITSEG_CHECK_ARG(tensor >= 0 && tensor < VITSEG_T_COUNT, VITSEG_EINVAL, "tensor id %d", tensor);
+    VITSEG_CHECK_ARG(!per_layer(tensor) || (layer >= 0 && layer < s.L), VITSEG_EINVAL, "layer %d out of range", layer);
+    const Layout l = make_layout(s);
+    if (offset_floats) *offset_floats = tensor_offset(l, tensor, layer);
+    if (numel) *numel = tensor_numel(s, tensor);
+    return VITSEG_OK;
+}
+
+int vitseg_cast_params_bf16(const float* params, void* params_bf16, size_t n_floats, void* stream) {
+    VITSEG_CHECK_ARG(params && params_bf16, VITSEG_EINVAL, "null arena");
+    return launch_cast_bf16(params, params_bf16, n_floats, (hipStream_t)stream);
+}
+
+int vitseg_query_workspace(const vitseg_config* cfg, int batch, int precision, size_t* bytes) {
+    Shape s;
+    if (int rc = check_config(cfg, &s)) return rc;
+    VITSEG_CHECK_ARG(batch >= 1 && bytes, VITSEG_EINVAL, "batch %d / null out pointer", batch);
+    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL, "precision %d", precision);
+    *bytes = make_plan(s, batch, precision).total;
+    return VITSEG_OK;
+}
+
+int vitseg_workspace_offset(const vitseg_config* cfg, int batch, int precision, int buffer, size_t* offset_bytes,
+                            size_t* bytes) {
+    Shape s;
+    if (int rc = check_config(cfg, &s)) return rc;
+    VITSEG_CHECK_ARG(batch >= 1, VITSEG_EINVAL, "batch %d", batch);
+    const Plan p = make_plan(s, batch, precision);
+    size_t o = 0, n = 0;
+    switch (buffer) {
+        case VITSEG_BUF_TOKENS: o = p.x; n = p.Mt * s.D * 4; break;
+        case VITSEG_BUF_LOWRES: o = p.z; n = (size_t)batch * s.C * s.Np * 4; break;
+        default: set_error("buffer id %d", buffer); return VITSEG_EINVAL;
+    }
+    if (offset_bytes) *offset_bytes = o;
+    if (bytes) *bytes = n;
+    return VITSEG_OK;
+}
+
+int vitseg_forward(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x, int batch,
+                   int precision, float* logits, uint8_t* mask, void* workspace, size_t workspace_bytes,
+                   void* stream_) {
+    Shape s;
+    if (int rc = check_config(cfg, &s)) return rc;
+    VITSEG_CHECK_ARG(params && x && workspace && batch >= 1, VITSEG_EINVAL, "null pointer or batch < 1");
+    VITSEG_CHECK_ARG(logits || mask, VITSEG_EINVAL, "both outputs are null");
+    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL, "precision %d", precision);
+    VITSEG_CHECK_ARG(precision == VITSEG_F32, VITSEG_EINVAL, "bf16 forward is not built yet");
+    VITSEG_CHECK_ARG(((uintptr_t)params | (uintptr_t)x | (uintptr_t)workspace | (uintptr_t)logits) % 16 == 0,
+                     VITSEG_EINVAL, "pointers must be 16-byte aligned");
+    (void)params_bf16;
+    const Plan p = make_plan(s, batch, precision);
+    VITSEG_CHECK_ARG(workspace_bytes >= p.total, VITSEG_EWORKSPACE, "workspace %zu < required %zu", workspace_bytes,
+                     p.total);
+    hipStream_t st = (hipStream_t)stream_;
+    const Layout lay = make_layout(s);
+    auto W = [&](int t, int layer = 0) { return params + tensor_offset(lay, t, layer); };
+    char* ws = (char*)workspace;
+    float* X = (float*)(ws + p.x);
+    float* H = (float*)(ws + p.h);
+    float* QKV = (float*)(ws + p.qkv);
+    float* U = (float*)(ws + p.u);
+    float* F = (float*)(ws + p.f);
+    float* Z = (float*)(ws + p.z);
+    const int Mt = (int)p.Mt, Mp = (int)p.Mp, D = s.D;
+    int rc;
+
+    // ---- embeddings (a2 + a3): patch GEMM gathers straight from the NCHW image ----
+    {
+        GemmArgs g{};
+        g.A = x; g.W = W(VITSEG_T_PATCH_W); g.bias = W(VITSEG_T_PATCH_B); g.R = W(VITSEG_T_POS); g.C = X;
+        g.M = Mp; g.N = D; g.K = s.Kp; g.lda = 0; g.ldc = D;
+        g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
+        if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st))) return rc;
+        if ((rc = launch_cls_rows(W(VITSEG_T_CLS), W(VITSEG_T_POS), X, batch, s.Np, D, st))) return rc;
+    }
+    // ---- encoder layers (a4..a8) ----
+    for (int l = 0; l < s.L; ++l) {
+        if ((rc = launch_layernorm(X, W(VITSEG_T_LN1_W, l), W(VITSEG_T_LN1_B, l), H, Mt, D, cfg->layer_norm_eps, false,
+                                   st)))
+            return rc;
+        GemmArgs g{};
+        g.A = H; g.W = W(VITSEG_T_WQKV, l); g.bias = W(VITSEG_T_BQKV, l); g.C = QKV;
+        g.M = Mt; g.N = 3 * D; g.K = D; g.lda = D; g.ldc = 3 * D;
+        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_BIAS, st))) return rc;
+        if ((rc = launch_attention_f32(QKV, H, batch, s.Np, s.A, st))) return rc;
+        g = GemmArgs{};
+        g.A = H; g.W = W(VITSEG_T_WO, l); g.bias = W(VITSEG_T_BO, l); g.R = X; g.C = X;
+        g.M = Mt; g.N = D; g.K = D; g.lda = D; g.ldc = D;
+        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_RESADD, st))) return rc;
+        if ((rc = launch_layernorm(X, W(VITSEG_T_LN2_W, l), W(VITSEG_T_LN2_B, l), H, Mt, D, cfg->layer_norm_eps, false,
+                                   st)))
+            return rc;
+        g = GemmArgs{};
+        g.A = H; g.W = W(VITSEG_T_W1, l); g.bias = W(VITSEG_T_B1, l); g.C = U;
+        g.M = Mt; g.N = s.I; g.K = D; g.lda = D; g.ldc = s.I;
+        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_GELU, st))) return rc;
+        g = GemmArgs{};
+        g.A = U; g.W = W(VITSEG_T_W2, l); g.bias = W(VITSEG_T_B2, l); g.R = X; g.C = X;
+        g.M = Mt; g.N = D; g.K = s.I; g.lda = s.I; g.ldc = D;
+        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_RESADD, st))) return rc;
+    }
+    // ---- final LayerNorm on the patch rows only (CLS is dropped, classes.py:250) ----
+    if ((rc = launch_layernorm(X, W(VITSEG_T_LNF_W), W(VITSEG_T_LNF_B), H, Mp, D, cfg->layer_norm_eps, false, st)))
+        return rc;
+    // ---- seg_head (a10 + a11): 3x3 conv as implicit GEMM over the token-major map ----
+    {
+        GemmArgs g{};
+        g.A = H; g.W = W(VITSEG_T_HEAD0_W); g.bias = W(VITSEG_T_HEAD0_B); g.C = F;
+        g.M = Mp; g.N = MID; g.K = 9 * D; g.lda = 0; g.ldc = MID;
+        g.g = s.g; g.Np = s.Np; g.D = D;
+        if ((rc = launch_gemm_f32(g, A_CONV3, EPI_RELU, st))) return rc;
+        if ((rc = launch_head1x1(F, W(VITSEG_T_HEAD2_W), W(VITSEG_T_HEAD2_B), Z, batch, s.Np, s.C, st))) return rc;
+    }
+    // ---- bilinear upsample (+ sigmoid -> argmax) (a12 + a14) ----
+    return launch_upsample(Z, logits, mask, batch, s.C, s.g, s.S, st);
+}
+
+// ---- single-operator entry points ---------------------------------------------------
+int vitseg_op_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps,
+                            void* stream) {
+    return launch_layernorm(x, w, b, y, rows, D, eps, false, (hipStream_t)stream);
+}
+
+int vitseg_op_linear_f32(const float* A, const float* Wt, const float* bias, const float* R, float* C, int M, int N,
+                         int K, int epilogue, void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "linear: null pointer");
+    VITSEG_CHECK_ARG(epilogue >= 0 && epilogue <= 3, VITSEG_EINVAL, "linear: epilogue %d", epilogue);
+    VITSEG_CHECK_ARG(epilogue != EPI_RESADD || R, VITSEG_EINVAL, "linear: residual epilogue needs R");
+    GemmArgs g{};
+    g.A = A; g.W = Wt; g.bias = bias; g.R = R; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
+    return launch_gemm_f32(g, A_PLAIN, epilogue, (hipStream_t)stream);
+}
+
+int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
+    return launch_attention_f32(qkv, ctx, batch, num_patches, num_heads, (hipStream_t)stream);
+}
+
+int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask, int batch, int C, int g, int S,
+                              void* stream) {
+    return launch_upsample(lowres, logits, mask, batch, C, g, S, (hipStream_t)stream);
+}
+
+}  // extern "C"

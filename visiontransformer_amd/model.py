@@ -1,0 +1,186 @@
+"""`ViTSegmentationModel` -- drop-in mirror of the reference class
+(/root/reference/model/CE/classes.py:221-262; byte-identical copy at model/PAED/classes.py:372-413).
+
+Same positional constructor, same `forward(x[B,3,H,W]) -> logits[B,C,H,W]`, same state-dict key
+schema, same ValueErrors; the arithmetic runs in libvitseg.so (hand-written gfx950 kernels) on
+the tensor's HIP stream.  PyTorch is storage only: one flat fp32 parameter arena (a single
+nn.Parameter), a cached workspace tensor and the output tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, params as _params
+from .config import ViTSegConfig
+
+_PRECISION = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.BF16, "bfloat16": _lib.BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class ViTSegmentationModel(nn.Module):
+    def __init__(self, num_classes, patch_size, hidden_size, num_hidden_layers, num_attention_heads, *,
+                 image_size: int = 224, intermediate_size: int = 3072, precision: str = "fp32",
+                 device=None):
+        super().__init__()
+        self.cfg = ViTSegConfig(num_classes, patch_size, hidden_size, num_hidden_layers, num_attention_heads,
+                                image_size=image_size, intermediate_size=intermediate_size)
+        self.precision = _PRECISION[precision]
+        n = _lib.param_count(self.cfg)  # validates the configuration (ValueError on unsupported shapes)
+        self.arena = nn.Parameter(torch.zeros(n, dtype=torch.float32, device=device))
+        self._views: Optional[Dict[str, torch.Tensor]] = None
+        self._views_key = None
+        self._ws = {}
+        self._arena_bf16 = None
+        self._bf16_version = None
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ parameters
+    def named_views(self) -> Dict[str, torch.Tensor]:
+        """reference parameter name -> live view into the arena."""
+        key = (self.arena.data_ptr(), self.arena.device)
+        if self._views is None or self._views_key != key:
+            self._views = _params.arena_views(self.cfg, self.arena.data)
+            self._views_key = key
+        return self._views
+
+    @torch.no_grad()
+    def reset_parameters(self, seed: int = 0):
+        """Initialisers of the reference: HF ViT init (N(0, 0.02) weights, zero biases, LayerNorm 1/0,
+        trunc-normal cls/pos; modeling_vit.py:324-332) and torch's Conv2d default for seg_head."""
+        g = torch.Generator().manual_seed(seed)
+        self.arena.zero_()
+        for name, v in self.named_views().items():
+            if name.startswith("seg_head."):
+                w = self.named_views()[name.rsplit(".", 1)[0] + ".weight"]
+                fan_in = w.shape[1] * w.shape[2] * w.shape[3]
+                bound = 1.0 / fan_in ** 0.5
+                v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * bound)
+            elif "layernorm" in name:
+                v.fill_(1.0 if name.endswith("weight") else 0.0)
+            elif name.endswith(".bias"):
+                v.zero_()
+            elif name.endswith("cls_token") or name.endswith("position_embeddings"):
+                v.copy_(torch.nn.init.trunc_normal_(torch.empty(v.shape), std=0.02, generator=g))
+            else:
+                v.copy_(torch.randn(v.shape, generator=g) * 0.02)
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        out = OrderedDict() if destination is None else destination
+        for k, v in self.named_views().items():
+            out[prefix + k] = v if keep_vars else v.detach().clone()
+        return out
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        views = self.named_views()
+        seen, unexpected = set(), []
+        for k, v in state_dict.items():
+            ck = _params.canonical_key(k)
+            if ck.startswith("backbone.pooler."):
+                continue  # computed then discarded by the reference (modeling_vit.py:386)
+            if ck not in views:
+                unexpected.append(k)
+                continue
+            if tuple(v.shape) != tuple(views[ck].shape):
+                raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model "
+                                   f"{tuple(views[ck].shape)}")
+            views[ck].copy_(torch.as_tensor(v).to(views[ck].device, torch.float32))
+            seen.add(ck)
+        missing = [k for k in views if k not in seen]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
+        self._bf16_version = None
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._views = None
+        self._ws.clear()
+        self._arena_bf16 = None
+        self._bf16_version = None
+        return r
+
+    # ------------------------------------------------------------------ launch plumbing
+    def _check_input(self, x: torch.Tensor):
+        cfg = self.cfg
+        if x.dim() != 4:
+            raise ValueError(f"expected a [B, C, H, W] tensor, got shape {tuple(x.shape)}")
+        if x.shape[1] != cfg.num_channels:  # modeling_vit.py:63-68
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the "
+                             f"configuration. Expected {cfg.num_channels} but got {x.shape[1]}.")
+        if x.shape[2] != cfg.image_size or x.shape[3] != cfg.image_size:  # modeling_vit.py:152-156
+            raise ValueError(f"Input image size ({x.shape[2]}*{x.shape[3]}) doesn't match model "
+                             f"({cfg.image_size}*{cfg.image_size}).")
+        if not x.is_cuda or x.device != self.arena.device:
+            raise RuntimeError("ViTSegmentationModel runs on the MI355X only: move the model and the input to the "
+                               f"same HIP device (input on {x.device}, parameters on {self.arena.device}). "
+                               "There is no CPU fallback.")
+
+    def workspace(self, batch: int) -> torch.Tensor:
+        key = (batch, self.precision)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = _lib.query_workspace(self.cfg, batch, self.precision)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.device)
+            self._ws = {key: ws}  # keep one: a new batch size replaces the old workspace
+        return ws
+
+    def _bf16_arena(self):
+        if self.precision != _lib.BF16:
+            return None
+        ver = (self.arena._version, self.arena.data_ptr())
+        if self._arena_bf16 is None or self._bf16_version != ver:
+            if self._arena_bf16 is None:
+                self._arena_bf16 = torch.empty(self.arena.numel(), dtype=torch.bfloat16, device=self.arena.device)
+            _lib.check(_lib.lib().vitseg_cast_params_bf16(self.arena.data_ptr(), self._arena_bf16.data_ptr(),
+                                                          self.arena.numel(),
+                                                          torch.cuda.current_stream().cuda_stream))
+            self._bf16_version = ver
+        return self._arena_bf16
+
+    def _run(self, x: torch.Tensor, want_logits: bool, want_mask: bool):
+        self._check_input(x)
+        x = x.to(torch.float32).contiguous()  # modeling_vit.py:369-371 casts to the weight dtype
+        B, S, Cc = x.shape[0], self.cfg.image_size, self.cfg.num_classes
+        logits = torch.empty((B, Cc, S, S), dtype=torch.float32, device=x.device) if want_logits else None
+        mask = torch.empty((B, S, S), dtype=torch.uint8, device=x.device) if want_mask else None
+        ws = self.workspace(B)
+        lp = self._bf16_arena()
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = _lib.lib().vitseg_forward(C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(),
+                                           _ptr(lp), x.data_ptr(), B, self.precision, _ptr(logits), _ptr(mask),
+                                           ws.data_ptr(), ws.numel(), stream)
+        _lib.check(rc)
+        return logits, mask
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """logits [B, C, H, W] (model/CE/classes.py:246-262), eval-mode arithmetic."""
+        if torch.is_grad_enabled() and self.arena.requires_grad and self.training:
+            raise NotImplementedError(
+                "training forward/backward through libvitseg is not built yet (round 1 ships inference); "
+                "call model.eval() / torch.no_grad() for inference")
+        logits, _ = self._run(x, True, False)
+        return logits
+
+    @torch.no_grad()
+    def predict_mask(self, x: torch.Tensor, return_logits: bool = False):
+        """uint8 [B, H, W] = argmax_c sigmoid(logits) with first-index ties, i.e. the reference scripts'
+        `logits.sigmoid()` + `argmax` (model/CE/testViTModel.py:122-126), fused into the decoder tail."""
+        logits, mask = self._run(x, return_logits, True)
+        return (mask, logits) if return_logits else mask
+
+    @torch.no_grad()
+    def debug_buffer(self, batch: int, which: int) -> torch.Tensor:
+        """fp32 view of a workspace buffer defined after forward (parity tests)."""
+        off, n = _lib.workspace_offset(self.cfg, batch, self.precision, which)
+        return self.workspace(batch)[off:off + n].view(torch.float32)
