@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Benchmark of the ViT-segmentation hot path on MI355X (contract: see the task prompt).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one per-GPU batch of synthetic 512x512 images that
+are already resident in HBM: ViTSegmentationModel forward -> fp32 logits [B,C,512,512] AND the
+uint8 sigmoid->argmax mask.  Workload at N=1 = BASELINE.json configs[1]: ViT-B/16 seg inference,
+batch 32 x 512x512, fp32.  N>1: one process per GPU, every rank runs the same per-GPU batch on
+its own shard of the global image stream (weak scaling, images are independent units; no
+data-path collective -- SURVEY.md section 8e); value = all ranks' images / max-over-ranks time.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel: hipEvent time measured inside the
+timed steps on the launch stream, algorithmic FLOPs per launch) and `cpu_baseline` (the oracle,
+a CPU port of the reference path, on a bounded sample on this box's host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from visiontransformer_amd import _lib, synth  # noqa: E402
+from visiontransformer_amd.config import vit_base16  # noqa: E402
+from visiontransformer_amd.model import ViTSegmentationModel  # noqa: E402
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
+KERNEL_NAMES = {  # kind -> kernel symbol as rocprofv3 prints it
+    "gemm_bias": "gemm_f32_kernel<0, 0>", "gemm_gelu": "gemm_f32_kernel<0, 1>",
+    "gemm_resadd": "gemm_f32_kernel<0, 2>", "gemm_patch": "gemm_f32_kernel<1, 4>",
+    "gemm_conv3": "gemm_f32_kernel<2, 3>", "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel",
+}
+
+
+def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.0):
+    """Times the oracle (CPU port of the reference model/CE path) on the first images of the batch
+    and uses the same run as the live parity check of the GPU output."""
+    from oracle import vitseg_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    n = min(2, images_np.shape[0])
+    x = torch.from_numpy(images_np[:n])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        logits = O.forward(x, sd, cfg)  # warm-up + parity reference
+        first = time.perf_counter() - t0
+        times = []
+        while sum(times) + first < seconds_budget and len(times) < 5:
+            t0 = time.perf_counter()
+            mask = O.predict_mask(O.forward(x, sd, cfg))
+            times.append(time.perf_counter() - t0)
+    t = float(np.median(times)) if times else first
+    err = float((gpu_logits[:n].cpu() - logits).abs().max())
+    srt = logits.sort(dim=1, descending=True).values
+    solid = (srt[:, 0] - srt[:, 1]) > 1e-4
+    match_all = float((gpu_mask[:n].cpu().long() == mask).float().mean())
+    match_solid = float((gpu_mask[:n].cpu().long() == mask)[solid].float().mean())
+    base = {"value": n / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (pure-torch restatement of model/CE forward + sigmoid/argmax), fp32, "
+                      f"{n} x {cfg.image_size}x{cfg.image_size} images, median of {max(len(times), 1)} runs"}
+    parity = {"logits_max_abs_err": err, "mask_match": match_all, "mask_match_margin_gt_1e-4": match_solid,
+              "images_checked": n}
+    return base, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = vit_base16(num_classes=2, image_size=512)
+    B = args.batch
+    model = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+                                 cfg.num_attention_heads, image_size=cfg.image_size,
+                                 precision={"f32": "fp32", "bf16": "bf16"}[args.precision], device=dev).eval()
+    sd_np = synth.make_state_dict(cfg, seed=1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    images_np = synth.make_images(cfg, B, seed=0, first_image=rank * B)  # this rank's shard of the image stream
+    x = torch.from_numpy(images_np).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            mask, logits = model.predict_mask(x, return_logits=True)
+        torch.cuda.synchronize()
+        barrier()
+        _lib.profile_enable(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mask, logits = model.predict_mask(x, return_logits=True)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        # dominant kernel = the MFMA kernel kind with the largest summed device time in the timed region
+        mfma = {k: v for k, v in prof.items() if k.startswith("gemm") or k == "attention"}
+        dom = max(mfma, key=lambda k: mfma[k]["ms"])
+        d = mfma[dom]
+        achieved = d["work"] / (d["ms"] * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        flops_img = cfg.forward_flops_per_image()
+        out = {
+            "metric": "images/sec (512×512) ViT-B/16 seg, 1/2/4/8 MI355X + mask argmax match",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"ViT-B/16 seg inference (forward -> fp32 logits + uint8 sigmoid/argmax mask), "
+                                   f"batch {B}/GPU x 512x512, {args.precision} (BASELINE.json configs[1])",
+                       "batch_per_gpu": B, "global_batch": B * world, "image_size": 512, "num_classes": 2,
+                       "parallelism": f"batch-split x{world}, no collective"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "kernel": KERNEL_NAMES.get(dom, dom), "launches": d["launches"],
+                         "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
+                         "flops_per_launch": d["work"] / max(d["launches"], 1)},
+            "whole_model": {"flops_per_image": flops_img,
+                            "achieved_tflops_per_gpu": round(value / world * flops_img / 1e12, 2),
+                            "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},
+            "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
+        }
+        if not args.no_cpu_baseline:
+            base, parity = cpu_baseline(cfg, sd_np, images_np, logits, mask)
+            out["cpu_baseline"] = base
+            out["parity"] = parity
+        print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

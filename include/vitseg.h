@@ -133,6 +133,28 @@ int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_pat
 int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask, int batch, int C, int g, int S,
                               void* stream);
 
+/* ---- measurement hooks (bench.py's roofline object) ----
+ * While enabled, vitseg_forward brackets every kernel launch of the hot path with a pair of
+ * hipEvents on the launch stream.  vitseg_profile_collect synchronises those events (the only
+ * call in this library that blocks) and returns, for one kernel kind, the summed device time,
+ * the number of launches and the algorithmic work of those launches (FLOPs for the MFMA kinds,
+ * HBM bytes for the bandwidth-bound kinds).  Process-global and not re-entrant: a debugging
+ * facility, off by default. */
+enum vitseg_kernel_kind {
+    VITSEG_K_GEMM_BIAS = 0, /* gemm kernel, plain A, bias epilogue      (QKV projection) */
+    VITSEG_K_GEMM_GELU,     /* gemm kernel, plain A, bias+GELU          (mlp.fc1) */
+    VITSEG_K_GEMM_RESADD,   /* gemm kernel, plain A, bias+residual      (o_proj, mlp.fc2) */
+    VITSEG_K_GEMM_PATCH,    /* gemm kernel, patchify loader, +pos       (patch embedding) */
+    VITSEG_K_GEMM_CONV3,    /* gemm kernel, 3x3 im2col loader, ReLU     (seg_head.0) */
+    VITSEG_K_ATTENTION,     /* flash attention core (patch queries) + CLS-query kernel */
+    VITSEG_K_LAYERNORM,     /* bytes */
+    VITSEG_K_HEAD1X1,       /* bytes */
+    VITSEG_K_UPSAMPLE,      /* bytes */
+    VITSEG_K_COUNT
+};
+int vitseg_profile_enable(int on);
+int vitseg_profile_collect(int kind, double* total_ms, int64_t* launches, double* work);
+
 #ifdef __cplusplus
 }
 #endif

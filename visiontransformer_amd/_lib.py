@@ -25,7 +25,10 @@ EXPORTS = [
     "vitseg_version", "vitseg_last_error", "vitseg_param_count", "vitseg_param_offset", "vitseg_cast_params_bf16",
     "vitseg_query_workspace", "vitseg_workspace_offset", "vitseg_forward", "vitseg_op_layernorm_f32",
     "vitseg_op_linear_f32", "vitseg_op_attention_f32", "vitseg_op_upsample_argmax",
+    "vitseg_profile_enable", "vitseg_profile_collect",
 ]
+KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
+                "head1x1", "upsample"]
 
 
 class CConfig(C.Structure):
@@ -65,6 +68,8 @@ def lib() -> C.CDLL:
         l.vitseg_op_linear_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_f32.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_upsample_argmax.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+        l.vitseg_profile_enable.argtypes = [i32]
+        l.vitseg_profile_collect.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         for name in EXPORTS:
             getattr(l, name)  # raises AttributeError if the build is stale
         _lib = l
@@ -105,3 +110,17 @@ def workspace_offset(cfg: ViTSegConfig, batch: int, precision: int, buffer: int)
     check(lib().vitseg_workspace_offset(C.byref(CConfig.from_config(cfg)), batch, precision, buffer,
                                         C.byref(off), C.byref(n)))
     return off.value, n.value
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().vitseg_profile_enable(1 if on else 0))
+
+
+def profile_collect() -> dict:
+    """kind -> dict(ms, launches, work) for every kernel kind recorded since profile_enable(True)."""
+    out = {}
+    for i, name in enumerate(KERNEL_KINDS):
+        ms, n, w = C.c_double(), C.c_int64(), C.c_double()
+        check(lib().vitseg_profile_collect(i, C.byref(ms), C.byref(n), C.byref(w)))
+        out[name] = dict(ms=ms.value, launches=n.value, work=w.value)
+    return out

@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <vector>
+
 #include "kernels.hpp"
 
 namespace vitseg {
@@ -156,6 +158,55 @@ Plan make_plan(const Shape& s, int B, int precision) {
     return p;
 }
 
+// ---- measurement hooks ----------------------------------------------------------
+struct ProfRec {
+    int kind;
+    double work;
+    hipEvent_t e0, e1;
+};
+struct Profiler {
+    bool on = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void clear() {
+        for (auto& r : recs) {
+            pool.push_back(r.e0);
+            pool.push_back(r.e1);
+        }
+        recs.clear();
+    }
+};
+Profiler g_prof;
+
+struct ProfScope {  // brackets the launches issued during its lifetime
+    hipStream_t st;
+    bool active;
+    ProfRec r;
+    ProfScope(int kind, double work, hipStream_t s) : st(s), active(g_prof.on) {
+        if (!active) return;
+        r.kind = kind;
+        r.work = work;
+        r.e0 = g_prof.get();
+        r.e1 = g_prof.get();
+        (void)hipEventRecord(r.e0, st);
+    }
+    ~ProfScope() {
+        if (!active) return;
+        (void)hipEventRecord(r.e1, st);
+        g_prof.recs.push_back(r);
+    }
+};
+
 }  // namespace
 }  // namespace vitseg
 
@@ -250,49 +301,94 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         g.A = x; g.W = W(VITSEG_T_PATCH_W); g.bias = W(VITSEG_T_PATCH_B); g.R = W(VITSEG_T_POS); g.C = X;
         g.M = Mp; g.N = D; g.K = s.Kp; g.lda = 0; g.ldc = D;
         g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
-        if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st))) return rc;
+        {
+            ProfScope ps(VITSEG_K_GEMM_PATCH, 2.0 * g.M * g.N * g.K, st);
+            if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st))) return rc;
+        }
         if ((rc = launch_cls_rows(W(VITSEG_T_CLS), W(VITSEG_T_POS), X, batch, s.Np, D, st))) return rc;
     }
     // ---- encoder layers (a4..a8) ----
+    const double ln_bytes = 2.0 * Mt * D * 4;
+    auto gemm = [&](const GemmArgs& g, int epi, int kind) {
+        ProfScope ps(kind, 2.0 * g.M * g.N * g.K, st);
+        return launch_gemm_f32(g, A_PLAIN, epi, st);
+    };
+    auto lnorm = [&](const float* w, const float* b, int rows) {
+        ProfScope ps(VITSEG_K_LAYERNORM, 2.0 * rows * D * 4, st);
+        return launch_layernorm(X, w, b, H, rows, D, cfg->layer_norm_eps, false, st);
+    };
+    (void)ln_bytes;
     for (int l = 0; l < s.L; ++l) {
-        if ((rc = launch_layernorm(X, W(VITSEG_T_LN1_W, l), W(VITSEG_T_LN1_B, l), H, Mt, D, cfg->layer_norm_eps, false,
-                                   st)))
-            return rc;
+        if ((rc = lnorm(W(VITSEG_T_LN1_W, l), W(VITSEG_T_LN1_B, l), Mt))) return rc;
         GemmArgs g{};
         g.A = H; g.W = W(VITSEG_T_WQKV, l); g.bias = W(VITSEG_T_BQKV, l); g.C = QKV;
         g.M = Mt; g.N = 3 * D; g.K = D; g.lda = D; g.ldc = 3 * D;
-        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_BIAS, st))) return rc;
-        if ((rc = launch_attention_f32(QKV, H, batch, s.Np, s.A, st))) return rc;
+        if ((rc = gemm(g, EPI_BIAS, VITSEG_K_GEMM_BIAS))) return rc;
+        {
+            ProfScope ps(VITSEG_K_ATTENTION, 4.0 * batch * s.A * (double)s.N * s.N * 64, st);
+            if ((rc = launch_attention_f32(QKV, H, batch, s.Np, s.A, st))) return rc;
+        }
         g = GemmArgs{};
         g.A = H; g.W = W(VITSEG_T_WO, l); g.bias = W(VITSEG_T_BO, l); g.R = X; g.C = X;
         g.M = Mt; g.N = D; g.K = D; g.lda = D; g.ldc = D;
-        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_RESADD, st))) return rc;
-        if ((rc = launch_layernorm(X, W(VITSEG_T_LN2_W, l), W(VITSEG_T_LN2_B, l), H, Mt, D, cfg->layer_norm_eps, false,
-                                   st)))
-            return rc;
+        if ((rc = gemm(g, EPI_RESADD, VITSEG_K_GEMM_RESADD))) return rc;
+        if ((rc = lnorm(W(VITSEG_T_LN2_W, l), W(VITSEG_T_LN2_B, l), Mt))) return rc;
         g = GemmArgs{};
         g.A = H; g.W = W(VITSEG_T_W1, l); g.bias = W(VITSEG_T_B1, l); g.C = U;
         g.M = Mt; g.N = s.I; g.K = D; g.lda = D; g.ldc = s.I;
-        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_GELU, st))) return rc;
+        if ((rc = gemm(g, EPI_GELU, VITSEG_K_GEMM_GELU))) return rc;
         g = GemmArgs{};
         g.A = U; g.W = W(VITSEG_T_W2, l); g.bias = W(VITSEG_T_B2, l); g.R = X; g.C = X;
         g.M = Mt; g.N = D; g.K = s.I; g.lda = s.I; g.ldc = D;
-        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_RESADD, st))) return rc;
+        if ((rc = gemm(g, EPI_RESADD, VITSEG_K_GEMM_RESADD))) return rc;
     }
     // ---- final LayerNorm on the patch rows only (CLS is dropped, classes.py:250) ----
-    if ((rc = launch_layernorm(X, W(VITSEG_T_LNF_W), W(VITSEG_T_LNF_B), H, Mp, D, cfg->layer_norm_eps, false, st)))
-        return rc;
+    if ((rc = lnorm(W(VITSEG_T_LNF_W), W(VITSEG_T_LNF_B), Mp))) return rc;
     // ---- seg_head (a10 + a11): 3x3 conv as implicit GEMM over the token-major map ----
     {
         GemmArgs g{};
         g.A = H; g.W = W(VITSEG_T_HEAD0_W); g.bias = W(VITSEG_T_HEAD0_B); g.C = F;
         g.M = Mp; g.N = MID; g.K = 9 * D; g.lda = 0; g.ldc = MID;
         g.g = s.g; g.Np = s.Np; g.D = D;
-        if ((rc = launch_gemm_f32(g, A_CONV3, EPI_RELU, st))) return rc;
+        {
+            ProfScope ps(VITSEG_K_GEMM_CONV3, 2.0 * g.M * g.N * g.K, st);
+            if ((rc = launch_gemm_f32(g, A_CONV3, EPI_RELU, st))) return rc;
+        }
+        ProfScope ps(VITSEG_K_HEAD1X1, (double)Mp * MID * 4 + (double)batch * s.C * s.Np * 4, st);
         if ((rc = launch_head1x1(F, W(VITSEG_T_HEAD2_W), W(VITSEG_T_HEAD2_B), Z, batch, s.Np, s.C, st))) return rc;
     }
     // ---- bilinear upsample (+ sigmoid -> argmax) (a12 + a14) ----
+    const double px = (double)batch * s.S * s.S;
+    ProfScope ps(VITSEG_K_UPSAMPLE, (logits ? px * s.C * 4 : 0.0) + (mask ? px : 0.0) + (double)batch * s.C * s.Np * 4,
+                 st);
     return launch_upsample(Z, logits, mask, batch, s.C, s.g, s.S, st);
+}
+
+int vitseg_profile_enable(int on) {
+    g_prof.clear();
+    g_prof.on = on != 0;
+    return VITSEG_OK;
+}
+
+int vitseg_profile_collect(int kind, double* total_ms, int64_t* launches, double* work) {
+    VITSEG_CHECK_ARG(kind >= 0 && kind < VITSEG_K_COUNT, VITSEG_EINVAL, "kernel kind %d", kind);
+    double ms = 0, w = 0;
+    int64_t n = 0;
+    for (auto& r : g_prof.recs) {
+        if (r.kind != kind) continue;
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, r.e0, r.e1);
+        if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime");
+        ms += t;
+        w += r.work;
+        ++n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (work) *work = w;
+    return VITSEG_OK;
 }
 
 // ---- single-operator entry points ---------------------------------------------------
