@@ -46,7 +46,8 @@ def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.
     """Times the oracle (CPU port of the reference model/CE path) on the first images of the batch
     and uses the same run as the live parity check of the GPU output."""
     from oracle import vitseg_oracle as O
-    cores = os.cpu_count() or 1
+    # the GPU box gives one-GPU jobs a 16-core share of the host; more threads than that oversubscribe
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VITSEG_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     n = min(2, images_np.shape[0])
@@ -54,6 +55,7 @@ def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.
     with torch.no_grad():
         t0 = time.perf_counter()
         logits = O.forward(x, sd, cfg)  # warm-up + parity reference
+        mask = O.predict_mask(logits)
         first = time.perf_counter() - t0
         times = []
         while sum(times) + first < seconds_budget and len(times) < 5:

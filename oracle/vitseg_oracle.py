@@ -176,7 +176,10 @@ def upsample_bilinear(z, size):
     As compiled for x86 with FMA the accumulation contracts to
         row = fma(a, wx0, b*wx1);   out = fma(row_top, wy0, row_bot*wy1)
     (established bit-for-bit against F.interpolate in oracle/make_golden.py's container:
-    0 mismatches over all golden cases; every other fma/no-fma placement mismatches >20%)."""
+    0 mismatches over all golden cases; every other fma/no-fma placement mismatches >20%).
+    Domain: output H + W > 128.  Below that ATen dispatches to a different (vectorised) kernel
+    (`_use_vectorized_kernel_cond_2d`, UpSampleKernel.cpp) whose rounding differs in the last
+    bit; every size the reference uses (224, and BASELINE's 512 / 1024) is in the domain."""
     H, W = size
     y0, y1, ly = bilinear_taps(z.shape[2], H, z.dtype)
     x0, x1, lx = bilinear_taps(z.shape[3], W, z.dtype)

@@ -98,7 +98,7 @@ def test_attention(B, Np, A):
     assert err < 2e-5, err  # fp32 exp2/softmax on O(1) values
 
 
-@pytest.mark.parametrize("B,C,g,S", [(2, 2, 14, 224), (1, 17, 14, 224), (1, 2, 32, 512), (1, 3, 28, 224), (1, 1, 8, 64)])
+@pytest.mark.parametrize("B,C,g,S", [(2, 2, 14, 224), (1, 17, 14, 224), (1, 2, 32, 512), (1, 3, 28, 224), (1, 1, 14, 112)])
 def test_upsample_sigmoid_argmax_bit_exact(B, C, g, S):
     z = _rand(B, C, g, g, seed=g + C, scale=2.0)
     if C >= 3:
