@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Launches one operator of libvitseg.so repeatedly (for rocprofv3 --pmc / --kernel-trace runs).
+
+    python3 tools/op_probe.py linear --M 32800 --N 3072 --K 768 --epi 1 --iters 10
+    python3 tools/op_probe.py attention --B 32 --Np 1024 --A 12
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visiontransformer_amd import _lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("op", choices=["linear", "attention", "layernorm"])
+ap.add_argument("--M", type=int, default=32800)
+ap.add_argument("--N", type=int, default=3072)
+ap.add_argument("--K", type=int, default=768)
+ap.add_argument("--epi", type=int, default=0)
+ap.add_argument("--B", type=int, default=32)
+ap.add_argument("--Np", type=int, default=1024)
+ap.add_argument("--A", type=int, default=12)
+ap.add_argument("--iters", type=int, default=10)
+a = ap.parse_args()
+dev = "cuda:0"
+st = torch.cuda.current_stream().cuda_stream
+L = _lib.lib()
+if a.op == "linear":
+    A = torch.randn(a.M, a.K, device=dev)
+    W = torch.randn(a.N, a.K, device=dev) * 0.05
+    b = torch.randn(a.N, device=dev)
+    C = torch.zeros(a.M, a.N, device=dev)
+    run = lambda: _lib.check(L.vitseg_op_linear_f32(A.data_ptr(), W.data_ptr(), b.data_ptr(), C.data_ptr(), C.data_ptr(),
+                                                    a.M, a.N, a.K, a.epi, st))
+    work = 2.0 * a.M * a.N * a.K
+elif a.op == "attention":
+    D = 64 * a.A
+    qkv = torch.randn(a.B * a.Np + a.B, 3 * D, device=dev)
+    ctx = torch.empty(a.B * a.Np + a.B, D, device=dev)
+    run = lambda: _lib.check(L.vitseg_op_attention_f32(qkv.data_ptr(), ctx.data_ptr(), a.B, a.Np, a.A, st))
+    work = 4.0 * a.B * a.A * (a.Np + 1) ** 2 * 64
+else:
+    x = torch.randn(a.M, a.K, device=dev)
+    w = torch.randn(a.K, device=dev)
+    y = torch.empty_like(x)
+    run = lambda: _lib.check(L.vitseg_op_layernorm_f32(x.data_ptr(), w.data_ptr(), w.data_ptr(), y.data_ptr(), a.M, a.K,
+                                                       1e-12, st))
+    work = 2.0 * a.M * a.K * 4
+run()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.iters):
+    run()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.iters
+print(f"{a.op}: {dt * 1e3:.3f} ms/launch, {work / dt / 1e12:.2f} T(FLOP|B)/s")

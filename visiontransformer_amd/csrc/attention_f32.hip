@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1);
+        gload(min(kt + 1, nkt - 1));  // the last tile re-stages itself: keeps the body branch-free
+        __builtin_amdgcn_sched_barrier(0);  // pin the issue point of the prefetch
         const float* Ks = lds[buf][0];
         const float* Vs = lds[buf][1];
 
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
                 }
             }
 
-        if (kt + 1 < nkt) swrite(buf ^ 1);
+        swrite(buf ^ 1);
         __syncthreads();
     }
 

@@ -58,36 +58,40 @@ __device__ __forceinline__ ARow<AMODE> make_arow(const GemmArgs& p, int m) {
     return r;
 }
 
+// Branch-free: out-of-range chunks read a safe in-bounds address and are zeroed by a select, so
+// the whole K step stays one basic block and the scheduler can spread the loads between MFMAs.
 template <int AMODE>
-__device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const ARow<AMODE>& r, int k) {
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    if (!r.valid || k >= p.K) return z;
+__device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const ARow<AMODE>& r, int k, bool& ok) {
+    ok = r.valid && k < p.K;
+    const int kc = min(k, p.K - 4);
+    const float* ptr;
     if (AMODE == A_PLAIN) {
-        return *(const f32x4*)(r.base + k);
+        ptr = r.base + kc;
     } else if (AMODE == A_PATCH) {
         const int pp = p.P * p.P;
-        const int c = k / pp, rem = k - c * pp;
+        const int c = kc / pp, rem = kc - c * pp;
         const int py = rem / p.P, px = rem - py * p.P;
-        return *(const f32x4*)(r.base + ((size_t)c * p.S + py) * p.S + px);
+        ptr = r.base + ((size_t)c * p.S + py) * p.S + px;
     } else {
-        const int tap = k / p.D, d = k - tap * p.D;
+        const int tap = kc / p.D, d = kc - tap * p.D;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int yy = r.y + ky - 1, xx = r.x + kx - 1;
-        if ((unsigned)yy >= (unsigned)p.g || (unsigned)xx >= (unsigned)p.g) return z;
-        return *(const f32x4*)(r.base + ((ptrdiff_t)(ky - 1) * p.g + (kx - 1)) * p.D + d);
+        const bool in = (unsigned)yy < (unsigned)p.g && (unsigned)xx < (unsigned)p.g;
+        ok = ok && in;
+        ptr = r.base + (in ? ((ptrdiff_t)(ky - 1) * p.g + (kx - 1)) * p.D : 0) + d;
     }
+    return *(const f32x4*)ptr;  // zeroed by the caller when !ok, at LDS-write time (keeps the load in flight)
 }
 
-template <int AMODE, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][BM * BK];  // [buffer][A|W][row*32 + swizzled chunk]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+// MI x NI MFMA tiles (32x32) per wave; rows start at a_row0, columns at b_col0 inside the block tile.
+//   <2,2>: the regular 2(M) x 2(N) wave grid, 64x64 per wave.
+//   <1,1>/<2,1>: "thin" row tiles (<= 32 / <= 64 valid rows: the CLS rows that follow the B*Np patch
+//   rows); the 4 waves split the 128 columns so such a tile costs 1/4 (1/2) of a regular one and is
+//   scheduled first, instead of adding a whole extra round of blocks to the launch.
+template <int AMODE, int EPI, int MI, int NI>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM * BK], int m0, int n0, int a_row0,
+                                          int b_col0) {
+    const int tid = threadIdx.x, lane = tid & 63;
 
     // ---- global -> register staging: thread owns chunk lc of rows lr + 32 i ----
     const int lc = tid & 7, lr = tid >> 3;
@@ -102,77 +106,106 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
         wrow[i] = (const float*)p.W + (size_t)(wvalid[i] ? n : 0) * p.K;
     }
     f32x4 ra[4], rb[4];
+    bool oka[4], okb[4];
     auto gload = [&](int kt) {
         const int k = kt * BK + lc * 4;
+        const int kc = min(k, p.K - 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = load_a<AMODE>(p, arow[i], k);
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            rb[i] = (wvalid[i] && k < p.K) ? *(const f32x4*)(wrow[i] + k) : z;
+            ra[i] = load_a<AMODE>(p, arow[i], k, oka[i]);
+            rb[i] = *(const f32x4*)(wrow[i] + kc);
+            okb[i] = wvalid[i] && k < p.K;
         }
     };
     const int wpos = lr * BK + ((lc ^ ((lr >> 1) & 7)) << 2);  // + 32*i rows -> same swizzle term
     auto swrite = [&](int buf) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(f32x4*)&lds[buf][0][wpos + 32 * i * BK] = ra[i];
-            *(f32x4*)&lds[buf][1][wpos + 32 * i * BK] = rb[i];
+            *(f32x4*)&lds[buf][0][wpos + 32 * i * BK] = oka[i] ? ra[i] : z;
+            *(f32x4*)&lds[buf][1][wpos + 32 * i * BK] = okb[i] ? rb[i] : z;
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int li = lane & 31, lh = lane >> 5;
     const int sw = (li >> 1) & 7;
-    const int a_off = (wm * 64 + li) * BK, b_off = (wn * 64 + li) * BK;
+    const int a_off = (a_row0 + li) * BK, b_off = (b_col0 + li) * BK;
+
+    // Fragment registers are double-buffered one MFMA group (16 MFMAs = 1024 matrix-pipe cycles)
+    // ahead, so no LDS latency is exposed: group j+1's ds_reads are issued before group j's MFMAs.
+    // The loop is rotated around the barrier: group 3 of tile kt runs AFTER the barrier that
+    // publishes tile kt+1, with tile kt+1's group-0 fragments already being read.
+    f32x4 a[2][MI], b[2][NI];
+    auto lfrag = [&](int buf, int j, int slot) {
+        const int ch = (((2 * j + lh) ^ sw) << 2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[slot][mi] = *(const f32x4*)&lds[buf][0][a_off + mi * 32 * BK + ch];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[slot][ni] = *(const f32x4*)&lds[buf][1][b_off + ni * 32 * BK + ch];
+    };
+    auto mfma_group = [&](int slot, int e0, int e1) {
+#pragma unroll
+        for (int e = e0; e < e1; ++e)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot][mi][e], b[slot][ni][e], acc[mi][ni], 0, 0, 0);
+    };
 
     const int KT = (p.K + BK - 1) / BK;
     gload(0);
     swrite(0);
     __syncthreads();
+    lfrag(0, 0, 0);
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) gload(kt + 1);
-        const float* As = lds[buf][0];
-        const float* Bs = lds[buf][1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ch = (((2 * j + lh) ^ sw) << 2);
-            f32x4 a[2], b[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const f32x4*)&As[a_off + mi * 32 * BK + ch];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const f32x4*)&Bs[b_off + ni * 32 * BK + ch];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
-        }
-        if (kt + 1 < KT) swrite(buf ^ 1);
+        const int kn = min(kt + 1, KT - 1);  // the last step re-stages its own tile: keeps the body branch-free
+        // group 0: next tile's global loads are issued here and stay in flight for ~2 groups
+        gload(kn);
+        lfrag(buf, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);  // pin: hipcc otherwise sinks the loads down to their use
+        mfma_group(0, 0, 4);
+        // group 1
+        lfrag(buf, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1, 0, 4);
+        // group 2: the staged tile is zero-masked and written to the idle LDS buffer mid-group
+        lfrag(buf, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        swrite(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0, 2, 4);
+        // group 3: one barrier hands the buffers over, then the next tile's first fragments are read
         __syncthreads();
+        lfrag(buf ^ 1, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1, 0, 4);
     }
 
     // ---- epilogue: acc reg r of lane (li, lh) = C[row (r&3) + 8 (r>>2) + 4 lh][col li] ----
     float* C = (float*)p.C;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + wn * 64 + ni * 32 + li;
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = n0 + b_col0 + ni * 32 + li;
         if (col >= p.N) continue;
         const float bias = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + a_row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= p.M) continue;
                 float v = acc[mi][ni][r] + bias;
                 if (EPI == EPI_GELU) v = gelu_erf(v);
@@ -183,6 +216,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
             }
         }
     }
+}
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][BM * BK];  // [buffer][A|W][row*32 + swizzled chunk]
+
+    const int wave = threadIdx.x >> 6;
+    // Two blocks share a CU, i.e. two waves share each SIMD's matrix pipe.  Running the same program
+    // under round-robin arbitration they advance in lockstep and reach their LDS/barrier phases
+    // together, leaving the pipe idle (measured: SQ_VALU_MFMA_BUSY 75 %).  A static priority by
+    // wave-slot parity lets one wave run ahead and the other fill its gaps.
+    if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)  // HW_REG_HW_ID.wave_id bit 0
+        __builtin_amdgcn_s_setprio(2);
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    // the last (possibly thin) row tile is placed first in the logical order
+    const int tm = t / tiles_n, tile_n = t - tm * tiles_n;
+    const int tile_m = tm == 0 ? tiles_m - 1 : tm - 1;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int rows_valid = p.M - m0;
+    if (rows_valid <= 32)
+        gemm_tile<AMODE, EPI, 1, 1>(p, lds, m0, n0, 0, wave * 32);
+    else if (rows_valid <= 64)
+        gemm_tile<AMODE, EPI, 2, 1>(p, lds, m0, n0, 0, wave * 32);
+    else
+        gemm_tile<AMODE, EPI, 2, 2>(p, lds, m0, n0, (wave >> 1) * 64, (wave & 1) * 64);
 }
 
 template <int AMODE, int EPI>

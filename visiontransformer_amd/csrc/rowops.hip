@@ -8,7 +8,10 @@ namespace {
 // eps from configuration_vit.py:58).  Biased variance, two-pass in registers (a row of up to
 // 2048 floats lives in one wave's registers), row reductions by wavefront butterfly.
 // One wave per row, 4 rows per block.  Bound: HBM (read D*4 + write D*{4,2} bytes per row).
-template <typename OutT>
+// NV = float4 vectors per lane (D <= 256*NV).  All loads of a row (x, then w and b) are issued
+// unconditionally up front -- out-of-range lanes re-read the last vector and are masked out of the
+// sums -- so a wave has its whole row in flight at once instead of one dependent load per branch.
+template <typename OutT, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, OutT* __restrict__ y, int rows,
                                                         int D, float eps) {
@@ -17,39 +20,40 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (row >= rows) return;
     const int nv = D >> 2;
     const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
-    f32x4 v[8];
+    f32x4 v[NV], wv[NV], bv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = xr[min(lane + 64 * i, nv - 1)];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        wv[i] = ((const f32x4*)w)[min(lane + 64 * i, nv - 1)];
+        bv[i] = ((const f32x4*)b)[min(lane + 64 * i, nv - 1)];
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            v[i] = xr[c];
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
+    for (int i = 0; i < NV; ++i) {
+        const float t = (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        s += (lane + 64 * i < nv) ? t : 0.f;
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
+    for (int i = 0; i < NV; ++i) {
+        float t = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[i][e] -= mean;
-                q = fmaf(v[i][e], v[i][e], q);
-            }
+        for (int e = 0; e < 4; ++e) {
+            v[i][e] -= mean;
+            t = fmaf(v[i][e], v[i][e], t);
         }
+        q += (lane + 64 * i < nv) ? t : 0.f;
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
-            const f32x4 wv = ((const f32x4*)w)[c];
-            const f32x4 bv = ((const f32x4*)b)[c];
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * wv[e] + bv[e];
+            for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * wv[i][e] + bv[i][e];
             if constexpr (sizeof(OutT) == 4) {
                 ((f32x4*)(y + (size_t)row * D))[c] = o;
             } else {
@@ -91,11 +95,22 @@ int launch_layernorm(const float* x, const float* w, const float* b, void* y, in
     VITSEG_CHECK_ARG(x && w && b && y && rows > 0, VITSEG_EINVAL, "layernorm: bad arguments");
     VITSEG_CHECK_ARG(D % 4 == 0 && D <= 2048, VITSEG_ESHAPE, "layernorm: D=%d must be a multiple of 4 and <= 2048", D);
     const dim3 grid((rows + 3) / 4);
-    if (out_bf16)
-        hipLaunchKernelGGL(layernorm_kernel<unsigned short>, grid, dim3(256), 0, s, x, w, b, (unsigned short*)y, rows,
-                           D, eps);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, w, b, (float*)y, rows, D, eps);
+    const int nvl = (D / 4 + 63) / 64;  // vectors per lane
+#define VITSEG_LN(NV)                                                                                              \
+    do {                                                                                                           \
+        if (out_bf16)                                                                                              \
+            hipLaunchKernelGGL((layernorm_kernel<unsigned short, NV>), grid, dim3(256), 0, s, x, w, b,            \
+                               (unsigned short*)y, rows, D, eps);                                                  \
+        else                                                                                                       \
+            hipLaunchKernelGGL((layernorm_kernel<float, NV>), grid, dim3(256), 0, s, x, w, b, (float*)y, rows, D,  \
+                               eps);                                                                               \
+    } while (0)
+    if (nvl <= 1) VITSEG_LN(1);
+    else if (nvl <= 2) VITSEG_LN(2);
+    else if (nvl <= 3) VITSEG_LN(3);
+    else if (nvl <= 4) VITSEG_LN(4);
+    else VITSEG_LN(8);
+#undef VITSEG_LN
     VITSEG_LAUNCH_CHECK("layernorm");
     return VITSEG_OK;
 }
