@@ -35,10 +35,17 @@ from visiontransformer_amd.config import vit_base16  # noqa: E402
 from visiontransformer_amd.model import ViTSegmentationModel  # noqa: E402
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
-KERNEL_NAMES = {  # kind -> kernel symbol as rocprofv3 prints it
-    "gemm_bias": "gemm_f32_kernel<0, 0>", "gemm_gelu": "gemm_f32_kernel<0, 1>",
-    "gemm_resadd": "gemm_f32_kernel<0, 2>", "gemm_patch": "gemm_f32_kernel<1, 4>",
-    "gemm_conv3": "gemm_f32_kernel<2, 3>", "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel",
+KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
+    "f32": {"gemm_bias": "gemm_kernel<float, float, 0, 0>", "gemm_gelu": "gemm_kernel<float, float, 0, 1>",
+            "gemm_resadd": "gemm_kernel<float, float, 0, 2>", "gemm_patch": "gemm_kernel<float, float, 1, 4>",
+            "gemm_conv3": "gemm_kernel<float, float, 2, 3>",
+            "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
+    "bf16": {"gemm_bias": "gemm_kernel<unsigned short, unsigned short, 0, 0>",
+             "gemm_gelu": "gemm_kernel<unsigned short, unsigned short, 0, 1>",
+             "gemm_resadd": "gemm_kernel<unsigned short, float, 0, 2>",
+             "gemm_patch": "gemm_kernel<float, float, 1, 4>",
+             "gemm_conv3": "gemm_kernel<unsigned short, float, 2, 3>",
+             "attention": "attn_bf16_kernel<false> + attn_cls_bf16_kernel"},
 }
 
 
@@ -156,7 +163,7 @@ def main():
                        "parallelism": f"batch-split x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
-                         "kernel": KERNEL_NAMES.get(dom, dom), "launches": d["launches"],
+                         "kernel": KERNEL_NAMES[args.precision].get(dom, dom), "launches": d["launches"],
                          "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                          "flops_per_launch": d["work"] / max(d["launches"], 1)},
             "whole_model": {"flops_per_image": flops_img,

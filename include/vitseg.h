@@ -129,6 +129,11 @@ int vitseg_op_linear_f32(const float* A, const float* W, const float* bias, cons
                          int K, int epilogue, void* stream);
 /* qkv: [B*Np + B, 3*A*64] rows as in the workspace; ctx: [B*Np + B, A*64] */
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream);
+/* bf16 operands (A, W as raw bf16 bits), fp32 accumulate; bias and R fp32.  C is bf16 for epilogues 0/1
+ * (tensors that feed the next MFMA) and fp32 for epilogue 2 (the residual stream). */
+int vitseg_op_linear_bf16(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N,
+                          int K, int epilogue, void* stream);
+int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream);
 /* lowres fp32 [B, C, g, g] -> logits fp32 [B, C, S, S] and/or mask uint8 [B, S, S] */
 int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask, int batch, int C, int g, int S,
                               void* stream);

@@ -25,7 +25,7 @@ EXPORTS = [
     "vitseg_version", "vitseg_last_error", "vitseg_param_count", "vitseg_param_offset", "vitseg_cast_params_bf16",
     "vitseg_query_workspace", "vitseg_workspace_offset", "vitseg_forward", "vitseg_op_layernorm_f32",
     "vitseg_op_linear_f32", "vitseg_op_attention_f32", "vitseg_op_upsample_argmax",
-    "vitseg_profile_enable", "vitseg_profile_collect",
+    "vitseg_profile_enable", "vitseg_profile_collect", "vitseg_op_linear_bf16", "vitseg_op_attention_bf16",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
                 "head1x1", "upsample"]
@@ -67,6 +67,8 @@ def lib() -> C.CDLL:
         l.vitseg_op_layernorm_f32.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp]
         l.vitseg_op_linear_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_f32.argtypes = [vp, vp, i32, i32, i32, vp]
+        l.vitseg_op_linear_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        l.vitseg_op_attention_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_upsample_argmax.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_profile_enable.argtypes = [i32]
         l.vitseg_profile_collect.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]

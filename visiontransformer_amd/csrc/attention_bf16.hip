@@ -1,0 +1,313 @@
+// Multi-head self-attention core, bf16 operands / fp32 softmax and accumulation:
+//   ctx = softmax(q k^T * hd^-0.5) v
+//
+// bf16 counterpart of attention_f32.hip (same reference lines:
+// transformers/models/vit/modeling_vit.py:164-189, :207-238; same "patches first" row layout,
+// CLS key folded into the initial online-softmax state, CLS queries in a side kernel).
+//
+// v_mfma_f32_32x32x16_bf16 for both products (bound: 2.5 PFLOP/s dense bf16; at head_dim 64 the
+// softmax VALU work per tile is comparable to the MFMA time, so the kernel is co-bound by VALU).
+//   S^T = K . Q^T : A = K rows from LDS (one ds_read_b128 per k-step), B = Q in registers.
+//       The accumulator puts a QUERY on each lane: max/sum/rescale are lane-local + one lane^32 swap.
+//   O^T = V^T . P^T : B = the exponentiated S^T registers 8s..8s+7 packed to bf16 (element j of lane
+//       half h is key 16s + 8(j>>2) + 4h + (j&3)), A = V^T gathered from the ROW-major V tile by two
+//       ds_read_b64_tr_b16 per k-step (hardware transpose; lane 4q+p of a 16-lane group supplies
+//       &V[key0+q][d0+4p] and receives V[key0..key0+3][d0 + lane] -- verified by tools/probes/tr16_probe.hip).
+// Scores are scaled inside the exponent: p = exp2(fma(s, c, -m*c)), c = hd^-0.5 * log2(e).
+#include "kernels.hpp"
+
+namespace vitseg {
+namespace {
+
+constexpr int HD = 64;   // head dim
+constexpr int QB = 128;  // queries per block (4 waves x 32)
+constexpr int KB = 64;   // keys per LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
+typedef unsigned short bf16_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16v2));  // v_cvt_pk_bf16_f32
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <bool RAGGED>
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                           int B, int Np, int A) {
+    // [buffer][K|V][key * 64 + d] bf16, rows of 128 B with XOR-swizzled 16-B chunks: 32 KiB
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][KB * HD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int D = A * HD, ld = 3 * D;
+    const size_t row0 = (size_t)b * Np;
+    const size_t cls_row = (size_t)B * Np + b;
+    const bf16_t* qbase = qkv + head * HD;
+    const bf16_t* kbase = qkv + D + head * HD;
+    const bf16_t* vbase = qkv + 2 * D + head * HD;
+    const float c = 0.125f * LOG2E;
+
+    // ---- this lane's query row: k-step s holds Q[16 s + 8 lh .. +7] (B operand of S^T) ----
+    const int q_local = blockIdx.x * QB + wave * 32 + li;
+    const bool q_valid = q_local < Np;
+    const size_t q_row = row0 + (q_valid ? q_local : Np - 1);
+    f32x4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const f32x4*)(qbase + q_row * ld + 16 * s + 8 * lh);
+
+    // ---- online-softmax state initialised with the CLS key (raw-score units) ----
+    float m_run, l_run;
+    f32x16 o[2];
+    {
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 kc = *(const f32x4*)(kbase + cls_row * ld + 16 * s + 8 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned qu = __float_as_uint(qf[s][e]), ku = __float_as_uint(kc[e]);
+                part = fmaf(bf_lo(qu), bf_lo(ku), part);
+                part = fmaf(bf_hi(qu), bf_hi(ku), part);
+            }
+        }
+        m_run = part + __shfl_xor(part, 32, 64);
+        l_run = lh == 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const uint2 t = *(const uint2*)(vbase + cls_row * ld + dt * 32 + 8 * g4 + 4 * lh);
+                o[dt][4 * g4 + 0] = bf_lo(t.x);
+                o[dt][4 * g4 + 1] = bf_hi(t.x);
+                o[dt][4 * g4 + 2] = bf_lo(t.y);
+                o[dt][4 * g4 + 3] = bf_hi(t.y);
+            }
+    }
+
+    // ---- K/V staging: thread owns 16-B chunk lc (8 bf16) of keys lr + 32 i ----
+    const int lc = tid & 7, lr = tid >> 3;
+    f32x4 rk[2], rv[2];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = kt * KB + lr + 32 * i;
+            if (RAGGED) key = min(key, Np - 1);  // duplicates are masked below
+            const size_t off = (row0 + key) * ld + 8 * lc;
+            rk[i] = *(const f32x4*)(kbase + off);
+            rv[i] = *(const f32x4*)(vbase + off);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = lr + 32 * i;
+            *(f32x4*)&lds[buf][0][key * HD + ((lc ^ ((key >> 1) & 7)) << 3)] = rk[i];        // K: row reads
+            *(f32x4*)&lds[buf][1][key * HD + ((lc ^ (((key >> 1) & 1) << 2)) << 3)] = rv[i];  // V: transposed reads
+        }
+    };
+    // per-lane LDS element offsets
+    const int k_off = li * HD;                 // + kb*32*HD, chunk (2s+lh) ^ ((li>>1)&7)
+    const int k_sw = (li >> 1) & 7;
+    const int g = lane & 15, grp = lane >> 4, tq = g >> 2, tp = g & 3;
+    // V^T fragment of (kb, s, dt): keys kb*32 + 16 s + 4 (grp>>1) + tq (+8), d = 32 dt + 16 (grp&1) + 4 tp
+    const int v_row = 4 * (grp >> 1) + tq;
+    const int v_sw = ((tq >> 1) & 1) << 2;
+    const int v_dchunk = 2 * (grp & 1) + (tp >> 1), v_half = (tp & 1) * 4;
+
+    const int nkt = (Np + KB - 1) / KB;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        gload(min(kt + 1, nkt - 1));  // the last tile re-stages itself: keeps the body branch-free
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16_t* Ks = lds[buf][0];
+        const bf16_t* Vs = lds[buf][1];
+
+        // S^T[key][query], two blocks of 32 keys
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 kf = *(const f32x4*)&Ks[kb * 32 * HD + k_off + (((2 * s + lh) ^ k_sw) << 3)];
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                 __builtin_bit_cast(bf16x8, qf[s]), st[kb], 0, 0, 0);
+            }
+        }
+        if (RAGGED) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * KB + kb * 32 + kappa(r, lh) >= Np) st[kb][r] = -INFINITY;
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+        const float mc = m_new * c;
+        float psum = 0.f;
+        unsigned pk[2][8];  // P^T fragments: pk[kb][4 s + w] = registers 8 s + 2 w, 8 s + 2 w + 1
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, -mc));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c, -mc));
+                psum += p0 + p1;
+                pk[kb][r >> 1] = pack_bf16(p0, p1);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // O^T[d][query] += V^T[d][key] . P^T[key][query]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = __builtin_bit_cast(
+                    bf16x8, (uint4){pk[kb][4 * s], pk[kb][4 * s + 1], pk[kb][4 * s + 2], pk[kb][4 * s + 3]});
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int row_a = kb * 32 + 16 * s + v_row;
+                    const int ch = (4 * dt + v_dchunk) ^ v_sw;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(Vs + row_a * HD + (ch << 3) + v_half));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(Vs + (row_a + 8) * HD + (ch << 3) + v_half));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+
+        swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds d = 32 dt + 8 g4 + 4 lh + e of its query ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_valid) {
+        bf16_t* out = ctx + q_row * (size_t)D + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 t;
+                t.x = pack_bf16(o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv);
+                t.y = pack_bf16(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+                *(uint2*)(out + dt * 32 + 8 * g4 + 4 * lh) = t;
+            }
+    }
+}
+
+// The B*A CLS queries: one block per (head, image); plain VALU in fp32 on bf16 inputs.
+__global__ __launch_bounds__(256) void attn_cls_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                            int B, int Np, int A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = Np + 1;
+    float* sc = sm;
+    float* red = sm + ((N + 63) & ~63);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int D = A * HD, ld = 3 * D;
+    const size_t row0 = (size_t)b * Np, cls_row = (size_t)B * Np + b;
+    const bf16_t* qp = qkv + cls_row * ld + head * HD;
+    const bf16_t* kbase = qkv + D + head * HD;
+    const bf16_t* vbase = qkv + 2 * D + head * HD;
+    const int sub = lane & 15, grp = lane >> 4;  // 16 lanes x 8 B cover one 64-element row
+
+    const uint2 qu = *(const uint2*)(qp + 4 * sub);
+    const float qs = 0.125f * LOG2E;
+    const float q0 = bf_lo(qu.x) * qs, q1 = bf_hi(qu.x) * qs, q2 = bf_lo(qu.y) * qs, q3 = bf_hi(qu.y) * qs;
+    for (int base = wave * 4; base < N; base += 16) {
+        const int key = base + grp;
+        float part = 0.f;
+        if (key < N) {
+            const size_t row = key < Np ? row0 + key : cls_row;
+            const uint2 ku = *(const uint2*)(kbase + row * ld + 4 * sub);
+            part = q0 * bf_lo(ku.x) + q1 * bf_hi(ku.x) + q2 * bf_lo(ku.y) + q3 * bf_hi(ku.y);
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        part += __shfl_xor(part, 8, 64);
+        if (sub == 0 && key < N) sc[key] = part;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < N; i += 256) {
+        const float pv = __builtin_amdgcn_exp2f(sc[i] - mx);
+        sc[i] = pv;
+        sum += pv;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    const int kg = tid >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int key = kg; key < N; key += 16) {
+        const size_t row = key < Np ? row0 + key : cls_row;
+        const uint2 vu = *(const uint2*)(vbase + row * ld + 4 * sub);
+        const float pv = sc[key];
+        acc[0] = fmaf(pv, bf_lo(vu.x), acc[0]);
+        acc[1] = fmaf(pv, bf_hi(vu.x), acc[1]);
+        acc[2] = fmaf(pv, bf_lo(vu.y), acc[2]);
+        acc[3] = fmaf(pv, bf_hi(vu.y), acc[3]);
+    }
+    *(f32x4*)&red[kg * 64 + 4 * sub] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+        for (int gI = 0; gI < 16; ++gI) s += red[gI * 64 + tid];
+        ctx[cls_row * (size_t)D + head * HD + tid] = f32_to_bf16(s * inv);
+    }
+}
+
+}  // namespace
+
+int launch_attention_bf16(const void* qkv, void* ctx, int B, int Np, int A, hipStream_t s) {
+    VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_bf16: bad arguments");
+    const dim3 grid((Np + QB - 1) / QB, A, B);
+    if (Np % QB == 0)
+        hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, B, Np, A);
+    else
+        hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, B, Np, A);
+    VITSEG_LAUNCH_CHECK("attn_bf16");
+    const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 16 * 64) * sizeof(float);
+    VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_bf16: sequence too long for the CLS kernel");
+    hipLaunchKernelGGL(attn_cls_bf16_kernel, dim3(A, B), dim3(256), smem, s, (const bf16_t*)qkv, (bf16_t*)ctx, B, Np,
+                       A);
+    VITSEG_LAUNCH_CHECK("attn_cls_bf16");
+    return VITSEG_OK;
+}
+
+}  // namespace vitseg

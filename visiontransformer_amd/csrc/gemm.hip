@@ -1,44 +1,51 @@
-// fp32 GEMM on the fp32-input matrix cores:  C[M,N] = epi(A[M,K] . W[N,K]^T + bias)
+// GEMM on the matrix cores:  C[M,N] = epi(A[M,K] . W[N,K]^T + bias),  fp32 or bf16 operands.
 //
 // Replaces aten::addmm / mkldnn_convolution behind nn.Linear / Conv2d in the reference
 // (56-65 % of the CPU profile): q/k/v/o projections and MLP
 // (transformers/models/vit/modeling_vit.py:207-254), patch embedding (:62-69) and
 // seg_head.0 (model/CE/classes.py:241) through the gathering A loaders.
 //
-// v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain (no TF32 on gfx950), 64 cycles per
-// issue per SIMD, so the kernel is matrix-pipe bound by a wide margin: per 128x128x32
-// block step a wave issues 64 MFMAs (4096 cycles) against 16 ds_read_b128 and 8 global
-// 16-byte loads.  Roofline: 157.3 TFLOP/s (fp32 matrix peak); HBM traffic is irrelevant.
+// T = float : v_mfma_f32_32x32x2_f32, an exact fp32 fmaf chain (no TF32 on gfx950), 64 cycles per
+//             issue per SIMD -> matrix-pipe bound by a wide margin (roofline 157.3 TFLOP/s).
+// T = bf16  : v_mfma_f32_32x32x16_bf16, fp32 accumulate, 32 cycles per issue (roofline 2.5 PFLOP/s);
+//             8x the FLOPs per staged byte, so this tile shape leans on L2 bandwidth.
 //
-// Tiling: block 128x128, BK = 32 floats (one 128-B line per operand row), 4 waves as
-// 2(M) x 2(N), each wave 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulator registers).
-// The k index inside a 32x32x2 MFMA is arbitrary as long as A and B agree, so lane half
-// h consumes k = 8j + 4h + e (j = 0..3, e = 0..3): each lane's four k-steps are ONE
-// 16-byte LDS read from a row-major [row][32] tile.  Rows are 128 B, so the 16-B chunk
-// index is XOR-swizzled with (row >> 1) & 7 to make ds_read_b128 conflict-free.
-// Global->LDS goes through registers (the gathering loaders need per-chunk predicates),
-// double-buffered in LDS with one barrier per K step.
+// Both element types share one structure because a staged operand row is 128 bytes either way:
+// block 128x128, BK = 128 B of K per row (32 floats / 64 bf16), 4 waves as 2(M) x 2(N), each wave
+// 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulator registers).  Lane half h consumes the 16-byte
+// chunks 2j+h (j = 0..3) of a row: for bf16 that chunk IS the 32x32x16 operand (k = 8h..8h+7 of
+// k-step j); for fp32 the k index inside a 32x32x2 MFMA is arbitrary as long as A and B agree, so
+// the chunk's four floats feed four consecutive MFMAs.  Either way a fragment is ONE ds_read_b128
+// from a row-major tile whose chunk index is XOR-swizzled with (row >> 1) & 7 (conflict-free).
+// Global->LDS goes through registers (the gathering loaders need per-chunk zero-fill),
+// double-buffered in LDS with one barrier per K step; fragments are double-buffered in registers.
 #include "kernels.hpp"
 
 namespace vitseg {
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BN = 128;
+constexpr int BKF = 32;    // row length in 4-byte LDS words
 
-template <int AMODE>
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int CE = 4, BKE = 32; };           // elements per chunk / per row
+template <> struct Elem<unsigned short> { static constexpr int CE = 8, BKE = 64; };  // bf16 bits
+typedef unsigned short bf16_t;
+
+template <typename T>
 struct ARow {
     // per-row state of the A loader, computed once (row is fixed for a thread)
-    const float* base;  // row base pointer (A_PLAIN / A_PATCH: image base of (b, gy, gx))
+    const T* base;  // row base pointer (A_PLAIN / A_PATCH: image base of (b, gy, gx))
     int y, x;           // A_CONV3: pixel coordinates
     bool valid;
 };
 
-template <int AMODE>
-__device__ __forceinline__ ARow<AMODE> make_arow(const GemmArgs& p, int m) {
-    ARow<AMODE> r;
+template <typename T, int AMODE>
+__device__ __forceinline__ ARow<T> make_arow(const GemmArgs& p, int m) {
+    ARow<T> r;
     r.valid = m < p.M;
     r.y = r.x = 0;
-    const float* A = (const float*)p.A;
+    const T* A = (const T*)p.A;
     if (!r.valid) {
         r.base = A;
         return r;
@@ -60,11 +67,11 @@ __device__ __forceinline__ ARow<AMODE> make_arow(const GemmArgs& p, int m) {
 
 // Branch-free: out-of-range chunks read a safe in-bounds address and are zeroed by a select, so
 // the whole K step stays one basic block and the scheduler can spread the loads between MFMAs.
-template <int AMODE>
-__device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const ARow<AMODE>& r, int k, bool& ok) {
+template <typename T, int AMODE>
+__device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const ARow<T>& r, int k, bool& ok) {
     ok = r.valid && k < p.K;
-    const int kc = min(k, p.K - 4);
-    const float* ptr;
+    const int kc = min(k, p.K - Elem<T>::CE);
+    const T* ptr;
     if (AMODE == A_PLAIN) {
         ptr = r.base + kc;
     } else if (AMODE == A_PATCH) {
@@ -88,31 +95,33 @@ __device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const ARow<AMODE>& r,
 //   <1,1>/<2,1>: "thin" row tiles (<= 32 / <= 64 valid rows: the CLS rows that follow the B*Np patch
 //   rows); the 4 waves split the 128 columns so such a tile costs 1/4 (1/2) of a regular one and is
 //   scheduled first, instead of adding a whole extra round of blocks to the launch.
-template <int AMODE, int EPI, int MI, int NI>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM * BK], int m0, int n0, int a_row0,
+template <typename T, typename OutT, int AMODE, int EPI, int MI, int NI>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM * BKF], int m0, int n0, int a_row0,
                                           int b_col0) {
+    constexpr int CE = Elem<T>::CE, BKE = Elem<T>::BKE;
+    constexpr int BK = BKF;  // LDS words per row
     const int tid = threadIdx.x, lane = tid & 63;
 
     // ---- global -> register staging: thread owns chunk lc of rows lr + 32 i ----
     const int lc = tid & 7, lr = tid >> 3;
-    ARow<AMODE> arow[4];
-    const float* wrow[4];
+    ARow<T> arow[4];
+    const T* wrow[4];
     bool wvalid[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        arow[i] = make_arow<AMODE>(p, m0 + lr + 32 * i);
+        arow[i] = make_arow<T, AMODE>(p, m0 + lr + 32 * i);
         const int n = n0 + lr + 32 * i;
         wvalid[i] = n < p.N;
-        wrow[i] = (const float*)p.W + (size_t)(wvalid[i] ? n : 0) * p.K;
+        wrow[i] = (const T*)p.W + (size_t)(wvalid[i] ? n : 0) * p.K;
     }
     f32x4 ra[4], rb[4];
     bool oka[4], okb[4];
     auto gload = [&](int kt) {
-        const int k = kt * BK + lc * 4;
-        const int kc = min(k, p.K - 4);
+        const int k = kt * BKE + lc * CE;
+        const int kc = min(k, p.K - CE);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = load_a<AMODE>(p, arow[i], k, oka[i]);
+            ra[i] = load_a<T, AMODE>(p, arow[i], k, oka[i]);
             rb[i] = *(const f32x4*)(wrow[i] + kc);
             okb[i] = wvalid[i] && k < p.K;
         }
@@ -151,18 +160,32 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) b[slot][ni] = *(const f32x4*)&lds[buf][1][b_off + ni * 32 * BK + ch];
     };
+    // one group = the MFMAs fed by one 16-byte chunk per operand: 4 k-steps of 32x32x2 (fp32, quarter
+    // q = one float of the chunk) or 1 k-step of 32x32x16 (bf16, issued with quarter 0)
     auto mfma_group = [&](int slot, int e0, int e1) {
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int e = e0; e < e1; ++e)
+            for (int e = e0; e < e1; ++e)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] =
-                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot][mi][e], b[slot][ni][e], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot][mi][e], b[slot][ni][e],
+                                                                           acc[mi][ni], 0, 0, 0);
+        } else {
+            if (e0 == 0) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[slot][mi]), __builtin_bit_cast(bf16x8, b[slot][ni]),
+                            acc[mi][ni], 0, 0, 0);
+            }
+        }
     };
 
-    const int KT = (p.K + BK - 1) / BK;
+    const int KT = (p.K + BKE - 1) / BKE;
     gload(0);
     swrite(0);
     __syncthreads();
@@ -195,7 +218,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
     }
 
     // ---- epilogue: acc reg r of lane (li, lh) = C[row (r&3) + 8 (r>>2) + 4 lh][col li] ----
-    float* C = (float*)p.C;
+    OutT* C = (OutT*)p.C;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int col = n0 + b_col0 + ni * 32 + li;
@@ -212,23 +235,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                 if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
                 if (EPI == EPI_RESADD) v = p.R[(size_t)row * p.ldc + col] + v;
                 if (EPI == EPI_POS) v += p.R[(size_t)(1 + row % p.Np) * p.N + col];
-                C[(size_t)row * p.ldc + col] = v;
+                if constexpr (sizeof(OutT) == 4)
+                    C[(size_t)row * p.ldc + col] = v;
+                else
+                    C[(size_t)row * p.ldc + col] = f32_to_bf16(v);
             }
         }
     }
 }
 
-template <int AMODE, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][BM * BK];  // [buffer][A|W][row*32 + swizzled chunk]
+template <typename T, typename OutT, int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][BM * BKF];  // [buffer][A|W][row*32 + swizzled chunk]
 
     const int wave = threadIdx.x >> 6;
-    // Two blocks share a CU, i.e. two waves share each SIMD's matrix pipe.  Running the same program
-    // under round-robin arbitration they advance in lockstep and reach their LDS/barrier phases
-    // together, leaving the pipe idle (measured: SQ_VALU_MFMA_BUSY 75 %).  A static priority by
-    // wave-slot parity lets one wave run ahead and the other fill its gaps.
-    if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)  // HW_REG_HW_ID.wave_id bit 0
-        __builtin_amdgcn_s_setprio(2);
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     // the last (possibly thin) row tile is placed first in the logical order
@@ -237,18 +257,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int rows_valid = p.M - m0;
     if (rows_valid <= 32)
-        gemm_tile<AMODE, EPI, 1, 1>(p, lds, m0, n0, 0, wave * 32);
+        gemm_tile<T, OutT, AMODE, EPI, 1, 1>(p, lds, m0, n0, 0, wave * 32);
     else if (rows_valid <= 64)
-        gemm_tile<AMODE, EPI, 2, 1>(p, lds, m0, n0, 0, wave * 32);
+        gemm_tile<T, OutT, AMODE, EPI, 2, 1>(p, lds, m0, n0, 0, wave * 32);
     else
-        gemm_tile<AMODE, EPI, 2, 2>(p, lds, m0, n0, (wave >> 1) * 64, (wave & 1) * 64);
+        gemm_tile<T, OutT, AMODE, EPI, 2, 2>(p, lds, m0, n0, (wave >> 1) * 64, (wave & 1) * 64);
 }
 
-template <int AMODE, int EPI>
+template <typename T, typename OutT, int AMODE, int EPI>
 int launch_one(const GemmArgs& a, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI>), dim3(tiles), dim3(256), 0, s, a);
-    VITSEG_LAUNCH_CHECK("gemm_f32");
+    hipLaunchKernelGGL((gemm_kernel<T, OutT, AMODE, EPI>), dim3(tiles), dim3(256), 0, s, a);
+    VITSEG_LAUNCH_CHECK("gemm");
     return VITSEG_OK;
 }
 
@@ -260,19 +280,39 @@ int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 4 == 0, VITSEG_EINVAL, "gemm_f32: lda %% 4");
         switch (epi) {
-            case EPI_BIAS: return launch_one<A_PLAIN, EPI_BIAS>(a, s);
-            case EPI_GELU: return launch_one<A_PLAIN, EPI_GELU>(a, s);
-            case EPI_RESADD: return launch_one<A_PLAIN, EPI_RESADD>(a, s);
-            case EPI_RELU: return launch_one<A_PLAIN, EPI_RELU>(a, s);
+            case EPI_BIAS: return launch_one<float, float, A_PLAIN, EPI_BIAS>(a, s);
+            case EPI_GELU: return launch_one<float, float, A_PLAIN, EPI_GELU>(a, s);
+            case EPI_RESADD: return launch_one<float, float, A_PLAIN, EPI_RESADD>(a, s);
+            case EPI_RELU: return launch_one<float, float, A_PLAIN, EPI_RELU>(a, s);
         }
     } else if (amode == A_PATCH && epi == EPI_POS) {
         VITSEG_CHECK_ARG(a.P % 4 == 0, VITSEG_ESHAPE, "patch size must be a multiple of 4");
-        return launch_one<A_PATCH, EPI_POS>(a, s);
+        return launch_one<float, float, A_PATCH, EPI_POS>(a, s);
     } else if (amode == A_CONV3 && epi == EPI_RELU) {
         VITSEG_CHECK_ARG(a.D % 4 == 0, VITSEG_ESHAPE, "hidden size must be a multiple of 4");
-        return launch_one<A_CONV3, EPI_RELU>(a, s);
+        return launch_one<float, float, A_CONV3, EPI_RELU>(a, s);
     }
     set_error("gemm_f32: unsupported amode/epilogue %d/%d", amode, epi);
+    return VITSEG_EINVAL;
+}
+
+// bf16 operands (A and W), fp32 accumulate.  Output type follows the consumer: bf16 for tensors
+// that feed the next MFMA (q|k|v, MLP hidden), fp32 for the residual stream and the head features.
+int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
+    VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 8 == 0, VITSEG_EINVAL, "gemm_bf16: bad M/N/K %d %d %d", a.M,
+                     a.N, a.K);
+    if (amode == A_PLAIN) {
+        VITSEG_CHECK_ARG(a.lda % 8 == 0, VITSEG_EINVAL, "gemm_bf16: lda %% 8");
+        switch (epi) {
+            case EPI_BIAS: return launch_one<bf16_t, bf16_t, A_PLAIN, EPI_BIAS>(a, s);
+            case EPI_GELU: return launch_one<bf16_t, bf16_t, A_PLAIN, EPI_GELU>(a, s);
+            case EPI_RESADD: return launch_one<bf16_t, float, A_PLAIN, EPI_RESADD>(a, s);
+        }
+    } else if (amode == A_CONV3 && epi == EPI_RELU) {
+        VITSEG_CHECK_ARG(a.D % 8 == 0, VITSEG_ESHAPE, "hidden size must be a multiple of 8");
+        return launch_one<bf16_t, float, A_CONV3, EPI_RELU>(a, s);
+    }
+    set_error("gemm_bf16: unsupported amode/epilogue %d/%d", amode, epi);
     return VITSEG_EINVAL;
 }
 

@@ -33,6 +33,7 @@ struct GemmArgs {
 };
 
 int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s);
+int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s);
 
 // LayerNorm over the last dim (a4); out_bf16 selects the bf16-output variant.
 int launch_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int D, float eps,
@@ -40,6 +41,7 @@ int launch_layernorm(const float* x, const float* w, const float* b, void* y, in
 
 // Multi-head self-attention core (a6) on the patches-first row layout.
 int launch_attention_f32(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s);
+int launch_attention_bf16(const void* qkv, void* ctx, int B, int Np, int A, hipStream_t s);
 
 // seg_head.2 (1x1 conv) on the ReLU'd mid features -> NCHW low-res logits (a11)
 int launch_head1x1(const float* F, const float* W2, const float* b2, float* Z, int B, int Np, int C, hipStream_t s);

@@ -275,21 +275,26 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     VITSEG_CHECK_ARG(params && x && workspace && batch >= 1, VITSEG_EINVAL, "null pointer or batch < 1");
     VITSEG_CHECK_ARG(logits || mask, VITSEG_EINVAL, "both outputs are null");
     VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL, "precision %d", precision);
-    VITSEG_CHECK_ARG(precision == VITSEG_F32, VITSEG_EINVAL, "bf16 forward is not built yet");
+    VITSEG_CHECK_ARG(precision == VITSEG_F32 || params_bf16, VITSEG_EINVAL, "bf16 forward needs the bf16 arena");
     VITSEG_CHECK_ARG(((uintptr_t)params | (uintptr_t)x | (uintptr_t)workspace | (uintptr_t)logits) % 16 == 0,
                      VITSEG_EINVAL, "pointers must be 16-byte aligned");
-    (void)params_bf16;
+    const bool lp = precision == VITSEG_BF16;
     const Plan p = make_plan(s, batch, precision);
     VITSEG_CHECK_ARG(workspace_bytes >= p.total, VITSEG_EWORKSPACE, "workspace %zu < required %zu", workspace_bytes,
                      p.total);
     hipStream_t st = (hipStream_t)stream_;
     const Layout lay = make_layout(s);
     auto W = [&](int t, int layer = 0) { return params + tensor_offset(lay, t, layer); };
+    // weight operand of a GEMM: fp32 arena or its bf16 shadow (same element offsets)
+    auto WG = [&](int t, int layer = 0) -> const void* {
+        const size_t off = tensor_offset(lay, t, layer);
+        return lp ? (const void*)((const unsigned short*)params_bf16 + off) : (const void*)(params + off);
+    };
     char* ws = (char*)workspace;
     float* X = (float*)(ws + p.x);
-    float* H = (float*)(ws + p.h);
-    float* QKV = (float*)(ws + p.qkv);
-    float* U = (float*)(ws + p.u);
+    void* H = (void*)(ws + p.h);      // fp32 or bf16 by precision
+    void* QKV = (void*)(ws + p.qkv);
+    void* U = (void*)(ws + p.u);
     float* F = (float*)(ws + p.f);
     float* Z = (float*)(ws + p.z);
     const int Mt = (int)p.Mt, Mp = (int)p.Mp, D = s.D;
@@ -311,34 +316,36 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     const double ln_bytes = 2.0 * Mt * D * 4;
     auto gemm = [&](const GemmArgs& g, int epi, int kind) {
         ProfScope ps(kind, 2.0 * g.M * g.N * g.K, st);
-        return launch_gemm_f32(g, A_PLAIN, epi, st);
+        return lp ? launch_gemm_bf16(g, A_PLAIN, epi, st) : launch_gemm_f32(g, A_PLAIN, epi, st);
     };
     auto lnorm = [&](const float* w, const float* b, int rows) {
-        ProfScope ps(VITSEG_K_LAYERNORM, 2.0 * rows * D * 4, st);
-        return launch_layernorm(X, w, b, H, rows, D, cfg->layer_norm_eps, false, st);
+        ProfScope ps(VITSEG_K_LAYERNORM, (double)rows * D * (lp ? 6 : 8), st);
+        return launch_layernorm(X, w, b, H, rows, D, cfg->layer_norm_eps, lp, st);
     };
     (void)ln_bytes;
     for (int l = 0; l < s.L; ++l) {
         if ((rc = lnorm(W(VITSEG_T_LN1_W, l), W(VITSEG_T_LN1_B, l), Mt))) return rc;
         GemmArgs g{};
-        g.A = H; g.W = W(VITSEG_T_WQKV, l); g.bias = W(VITSEG_T_BQKV, l); g.C = QKV;
+        g.A = H; g.W = WG(VITSEG_T_WQKV, l); g.bias = W(VITSEG_T_BQKV, l); g.C = QKV;
         g.M = Mt; g.N = 3 * D; g.K = D; g.lda = D; g.ldc = 3 * D;
         if ((rc = gemm(g, EPI_BIAS, VITSEG_K_GEMM_BIAS))) return rc;
         {
             ProfScope ps(VITSEG_K_ATTENTION, 4.0 * batch * s.A * (double)s.N * s.N * 64, st);
-            if ((rc = launch_attention_f32(QKV, H, batch, s.Np, s.A, st))) return rc;
+            rc = lp ? launch_attention_bf16(QKV, H, batch, s.Np, s.A, st)
+                    : launch_attention_f32((const float*)QKV, (float*)H, batch, s.Np, s.A, st);
+            if (rc) return rc;
         }
         g = GemmArgs{};
-        g.A = H; g.W = W(VITSEG_T_WO, l); g.bias = W(VITSEG_T_BO, l); g.R = X; g.C = X;
+        g.A = H; g.W = WG(VITSEG_T_WO, l); g.bias = W(VITSEG_T_BO, l); g.R = X; g.C = X;
         g.M = Mt; g.N = D; g.K = D; g.lda = D; g.ldc = D;
         if ((rc = gemm(g, EPI_RESADD, VITSEG_K_GEMM_RESADD))) return rc;
         if ((rc = lnorm(W(VITSEG_T_LN2_W, l), W(VITSEG_T_LN2_B, l), Mt))) return rc;
         g = GemmArgs{};
-        g.A = H; g.W = W(VITSEG_T_W1, l); g.bias = W(VITSEG_T_B1, l); g.C = U;
+        g.A = H; g.W = WG(VITSEG_T_W1, l); g.bias = W(VITSEG_T_B1, l); g.C = U;
         g.M = Mt; g.N = s.I; g.K = D; g.lda = D; g.ldc = s.I;
         if ((rc = gemm(g, EPI_GELU, VITSEG_K_GEMM_GELU))) return rc;
         g = GemmArgs{};
-        g.A = U; g.W = W(VITSEG_T_W2, l); g.bias = W(VITSEG_T_B2, l); g.R = X; g.C = X;
+        g.A = U; g.W = WG(VITSEG_T_W2, l); g.bias = W(VITSEG_T_B2, l); g.R = X; g.C = X;
         g.M = Mt; g.N = D; g.K = s.I; g.lda = s.I; g.ldc = D;
         if ((rc = gemm(g, EPI_RESADD, VITSEG_K_GEMM_RESADD))) return rc;
     }
@@ -347,12 +354,13 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     // ---- seg_head (a10 + a11): 3x3 conv as implicit GEMM over the token-major map ----
     {
         GemmArgs g{};
-        g.A = H; g.W = W(VITSEG_T_HEAD0_W); g.bias = W(VITSEG_T_HEAD0_B); g.C = F;
+        g.A = H; g.W = WG(VITSEG_T_HEAD0_W); g.bias = W(VITSEG_T_HEAD0_B); g.C = F;
         g.M = Mp; g.N = MID; g.K = 9 * D; g.lda = 0; g.ldc = MID;
         g.g = s.g; g.Np = s.Np; g.D = D;
         {
             ProfScope ps(VITSEG_K_GEMM_CONV3, 2.0 * g.M * g.N * g.K, st);
-            if ((rc = launch_gemm_f32(g, A_CONV3, EPI_RELU, st))) return rc;
+            rc = lp ? launch_gemm_bf16(g, A_CONV3, EPI_RELU, st) : launch_gemm_f32(g, A_CONV3, EPI_RELU, st);
+            if (rc) return rc;
         }
         ProfScope ps(VITSEG_K_HEAD1X1, (double)Mp * MID * 4 + (double)batch * s.C * s.Np * 4, st);
         if ((rc = launch_head1x1(F, W(VITSEG_T_HEAD2_W), W(VITSEG_T_HEAD2_B), Z, batch, s.Np, s.C, st))) return rc;
@@ -406,6 +414,21 @@ int vitseg_op_linear_f32(const float* A, const float* Wt, const float* bias, con
     g.A = A; g.W = Wt; g.bias = bias; g.R = R; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
     return launch_gemm_f32(g, A_PLAIN, epilogue, (hipStream_t)stream);
+}
+
+int vitseg_op_linear_bf16(const void* A, const void* Wt, const float* bias, const float* R, void* C, int M, int N,
+                          int K, int epilogue, void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "linear: null pointer");
+    VITSEG_CHECK_ARG(epilogue >= 0 && epilogue <= 2, VITSEG_EINVAL, "linear_bf16: epilogue %d", epilogue);
+    VITSEG_CHECK_ARG(epilogue != EPI_RESADD || R, VITSEG_EINVAL, "linear: residual epilogue needs R");
+    GemmArgs g{};
+    g.A = A; g.W = Wt; g.bias = bias; g.R = R; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
+    return launch_gemm_bf16(g, A_PLAIN, epilogue, (hipStream_t)stream);
+}
+
+int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream) {
+    return launch_attention_bf16(qkv, ctx, batch, num_patches, num_heads, (hipStream_t)stream);
 }
 
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
