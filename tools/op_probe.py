@@ -24,11 +24,26 @@ ap.add_argument("--B", type=int, default=32)
 ap.add_argument("--Np", type=int, default=1024)
 ap.add_argument("--A", type=int, default=12)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--bf16", action="store_true")
 a = ap.parse_args()
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 L = _lib.lib()
-if a.op == "linear":
+if a.op == "linear" and a.bf16:
+    A = torch.randn(a.M, a.K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(a.N, a.K, device=dev) * 0.05).to(torch.bfloat16)
+    b = torch.randn(a.N, device=dev)
+    C = torch.zeros(a.M, a.N, device=dev, dtype=torch.float32 if a.epi == 2 else torch.bfloat16)
+    run = lambda: _lib.check(L.vitseg_op_linear_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), C.data_ptr(), C.data_ptr(),
+                                                     a.M, a.N, a.K, a.epi, st))
+    work = 2.0 * a.M * a.N * a.K
+elif a.op == "attention" and a.bf16:
+    D = 64 * a.A
+    qkv = torch.randn(a.B * a.Np + a.B, 3 * D, device=dev).to(torch.bfloat16)
+    ctx = torch.empty(a.B * a.Np + a.B, D, device=dev, dtype=torch.bfloat16)
+    run = lambda: _lib.check(L.vitseg_op_attention_bf16(qkv.data_ptr(), ctx.data_ptr(), a.B, a.Np, a.A, st))
+    work = 4.0 * a.B * a.A * (a.Np + 1) ** 2 * 64
+elif a.op == "linear":
     A = torch.randn(a.M, a.K, device=dev)
     W = torch.randn(a.N, a.K, device=dev) * 0.05
     b = torch.randn(a.N, device=dev)

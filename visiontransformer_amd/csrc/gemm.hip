@@ -102,40 +102,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
     constexpr int BK = BKF;  // LDS words per row
     const int tid = threadIdx.x, lane = tid & 63;
 
-    // ---- global -> register staging: thread owns chunk lc of rows lr + 32 i ----
-    const int lc = tid & 7, lr = tid >> 3;
-    ARow<T> arow[4];
-    const T* wrow[4];
-    bool wvalid[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        arow[i] = make_arow<T, AMODE>(p, m0 + lr + 32 * i);
-        const int n = n0 + lr + 32 * i;
-        wvalid[i] = n < p.N;
-        wrow[i] = (const T*)p.W + (size_t)(wvalid[i] ? n : 0) * p.K;
-    }
-    f32x4 ra[4], rb[4];
-    bool oka[4], okb[4];
-    auto gload = [&](int kt) {
-        const int k = kt * BKE + lc * CE;
-        const int kc = min(k, p.K - CE);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = load_a<T, AMODE>(p, arow[i], k, oka[i]);
-            rb[i] = *(const f32x4*)(wrow[i] + kc);
-            okb[i] = wvalid[i] && k < p.K;
-        }
-    };
-    const int wpos = lr * BK + ((lc ^ ((lr >> 1) & 7)) << 2);  // + 32*i rows -> same swizzle term
-    auto swrite = [&](int buf) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(f32x4*)&lds[buf][0][wpos + 32 * i * BK] = oka[i] ? ra[i] : z;
-            *(f32x4*)&lds[buf][1][wpos + 32 * i * BK] = okb[i] ? rb[i] : z;
-        }
-    };
-
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -186,59 +152,199 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
     };
 
     const int KT = (p.K + BKE - 1) / BKE;
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    lfrag(0, 0, 0);
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        const int kn = min(kt + 1, KT - 1);  // the last step re-stages its own tile: keeps the body branch-free
-        // group 0: next tile's global loads are issued here and stay in flight for ~2 groups
-        gload(kn);
-        lfrag(buf, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);  // pin: hipcc otherwise sinks the loads down to their use
-        mfma_group(0, 0, 4);
-        // group 1
-        lfrag(buf, 2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(1, 0, 4);
-        // group 2: the staged tile is zero-masked and written to the idle LDS buffer mid-group
-        lfrag(buf, 3, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(0, 0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        swrite(buf ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(0, 2, 4);
-        // group 3: one barrier hands the buffers over, then the next tile's first fragments are read
+    if constexpr (sizeof(T) == 4) {
+        // ---- global -> register staging: thread owns chunk lc of rows lr + 32 i ----
+        const int lc = tid & 7, lr = tid >> 3;
+        ARow<T> arow[4];
+        const T* wrow[4];
+        bool wvalid[4];
+    #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            arow[i] = make_arow<T, AMODE>(p, m0 + lr + 32 * i);
+            const int n = n0 + lr + 32 * i;
+            wvalid[i] = n < p.N;
+            wrow[i] = (const T*)p.W + (size_t)(wvalid[i] ? n : 0) * p.K;
+        }
+        f32x4 ra[4], rb[4];
+        bool oka[4], okb[4];
+        auto gload = [&](int kt) {
+            const int k = kt * BKE + lc * CE;
+            const int kc = min(k, p.K - CE);
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = load_a<T, AMODE>(p, arow[i], k, oka[i]);
+                rb[i] = *(const f32x4*)(wrow[i] + kc);
+                okb[i] = wvalid[i] && k < p.K;
+            }
+        };
+        const int wpos = lr * BK + ((lc ^ ((lr >> 1) & 7)) << 2);  // + 32*i rows -> same swizzle term
+        auto swrite = [&](int buf) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *(f32x4*)&lds[buf][0][wpos + 32 * i * BK] = oka[i] ? ra[i] : z;
+                *(f32x4*)&lds[buf][1][wpos + 32 * i * BK] = okb[i] ? rb[i] : z;
+            }
+        };
+        gload(0);
+        swrite(0);
         __syncthreads();
-        lfrag(buf ^ 1, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(1, 0, 4);
+        lfrag(0, 0, 0);
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            const int kn = min(kt + 1, KT - 1);  // the last step re-stages its own tile: keeps the body branch-free
+            // group 0: next tile's global loads are issued here and stay in flight for ~2 groups
+            gload(kn);
+            lfrag(buf, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);  // pin: hipcc otherwise sinks the loads down to their use
+            mfma_group(0, 0, 4);
+            // group 1
+            lfrag(buf, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(1, 0, 4);
+            // group 2: the staged tile is zero-masked and written to the idle LDS buffer mid-group
+            lfrag(buf, 3, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(0, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            swrite(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(0, 2, 4);
+            // group 3: one barrier hands the buffers over, then the next tile's first fragments are read
+            __syncthreads();
+            lfrag(buf ^ 1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(1, 0, 4);
+        }
+    } else {
+        // ---- bf16: global -> LDS directly (global_load_lds_dwordx4), no staging registers, no VALU ----
+        // One wave instruction fills 1 KiB = 8 staged rows, lane l -> row l>>3, LDS chunk position l&7.
+        // The LDS image is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk
+        // (position p of row r holds logical chunk p ^ ((r>>1)&7)) and again on the fragment reads.
+        // Rows beyond M / N are clamped (their results are never stored); 3x3 taps outside the image
+        // read a zero page.  Requires K % 64 == 0 (checked by the launcher).
+        const int wave = tid >> 6;
+        const T* asrc[4];
+        const T* wsrc[4];
+        int ay[4], ax[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + (lane >> 3);
+            const int cpos = (lane & 7) ^ ((row >> 1) & 7);
+            const int m = min(m0 + row, p.M - 1), n = min(n0 + row, p.N - 1);
+            wsrc[i] = (const T*)p.W + (size_t)n * p.K + cpos * CE;
+            if (AMODE == A_PLAIN) {
+                asrc[i] = (const T*)p.A + (size_t)m * p.lda + cpos * CE;
+                ay[i] = ax[i] = 0;
+            } else {  // A_CONV3
+                const int bimg = m / p.Np, t = m - bimg * p.Np;
+                ay[i] = t / p.g;
+                ax[i] = t - ay[i] * p.g;
+                asrc[i] = (const T*)p.A + (size_t)m * p.D + cpos * CE;
+            }
+        }
+        auto issue = [&](int kt, int buf) {
+            const int k0 = kt * BKE;
+            int tap = 0, d0 = k0, ky = 1, kx = 1;
+            if (AMODE == A_CONV3) {
+                tap = k0 / p.D;  // a 64-wide K step lies inside one tap (D % 64 == 0)
+                d0 = k0 - tap * p.D;
+                ky = tap / 3;
+                kx = tap - ky * 3;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const T* ga;
+                if (AMODE == A_PLAIN) {
+                    ga = asrc[i] + k0;
+                } else {
+                    const int yy = ay[i] + ky - 1, xx = ax[i] + kx - 1;
+                    const bool in = (unsigned)yy < (unsigned)p.g && (unsigned)xx < (unsigned)p.g;
+                    ga = in ? asrc[i] + ((ptrdiff_t)(ky - 1) * p.g + (kx - 1)) * p.D + d0
+                            : (const T*)p.zeros + ((lane & 7) ^ 0) * CE;
+                }
+                const int lrow = (wave * 4 + i) * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                                 (__attribute__((address_space(3))) void*)&lds[buf][0][lrow * BK], 16,
+                                                 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)&lds[buf][1][lrow * BK], 16,
+                                                 0, 0);
+            }
+        };
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (KT > 1) issue(1, 1);
+        lfrag(0, 0, 0);
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            lfrag(buf, 1, 1);
+            mfma_group(0, 0, 4);
+            lfrag(buf, 2, 0);
+            mfma_group(1, 0, 4);
+            lfrag(buf, 3, 1);
+            mfma_group(0, 0, 4);
+            // tile kt+1 (issued one K step ago) must have landed for every wave, and every wave's
+            // reads of this buffer must be complete before it is refilled
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < KT) issue(kt + 2, buf);
+            lfrag(buf ^ 1, 0, 0);
+            mfma_group(1, 0, 4);
+        }
     }
 
-    // ---- epilogue: acc reg r of lane (li, lh) = C[row (r&3) + 8 (r>>2) + 4 lh][col li] ----
-    OutT* C = (OutT*)p.C;
+    // ---- epilogue, staged through LDS so that global traffic is whole rows ----
+    // acc reg r of lane (li, lh) = C[row (r&3) + 8 (r>>2) + 4 lh][col li]: one column per lane, which
+    // would mean 64 scattered 2/4-byte stores per lane.  Each wave instead parks its sub-tile in its own
+    // 16 KiB of the (now idle) operand buffers and re-reads it row-wise: 4 consecutive columns per
+    // lane, so bias / residual / output move as 16-byte (fp32) or 8-byte (bf16) vectors along rows.
+    __syncthreads();  // every wave is done with the operand tiles
+    {
+        const int wave = tid >> 6;
+        float* wl = &lds[0][0][0] + wave * 4096;  // [64 rows][64 cols] fp32, wave-private
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int col = n0 + b_col0 + ni * 32 + li;
-        if (col >= p.N) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + a_row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= p.M) continue;
-                float v = acc[mi][ni][r] + bias;
-                if (EPI == EPI_GELU) v = gelu_erf(v);
-                if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-                if (EPI == EPI_RESADD) v = p.R[(size_t)row * p.ldc + col] + v;
-                if (EPI == EPI_POS) v += p.R[(size_t)(1 + row % p.Np) * p.N + col];
-                if constexpr (sizeof(OutT) == 4)
-                    C[(size_t)row * p.ldc + col] = v;
-                else
-                    C[(size_t)row * p.ldc + col] = f32_to_bf16(v);
+                for (int r = 0; r < 16; ++r)
+                    wl[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + ni * 32 + li] = acc[mi][ni][r];
+        constexpr int LPR = NI * 8;        // lanes per row (4 columns each)
+        constexpr int RPP = 64 / LPR;      // rows per pass
+        const int rr = lane / LPR, c4 = (lane % LPR) * 4;
+        const int gcol = n0 + b_col0 + c4;
+        if (gcol < p.N) {
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bias4 = *(const f32x4*)(p.bias + gcol);
+            OutT* C = (OutT*)p.C;
+#pragma unroll
+            for (int ps = 0; ps < MI * 32 / RPP; ++ps) {
+                const int row = ps * RPP + rr;
+                const int grow = m0 + a_row0 + row;
+                if (grow >= p.M) continue;
+                f32x4 v = *(const f32x4*)&wl[row * 64 + c4];
+                const size_t o = (size_t)grow * p.ldc + gcol;
+                f32x4 extra = {0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_RESADD) extra = *(const f32x4*)(p.R + o);
+                if (EPI == EPI_POS) extra = *(const f32x4*)(p.R + (size_t)(1 + grow % p.Np) * p.N + gcol);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e] + bias4[e];
+                    if (EPI == EPI_GELU) x = (sizeof(T) == 4) ? gelu_erf(x) : gelu_erf_fast(x);
+                    if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
+                    if (EPI == EPI_RESADD || EPI == EPI_POS) x = extra[e] + x;
+                    v[e] = x;
+                }
+                if constexpr (sizeof(OutT) == 4) {
+                    *(f32x4*)(C + o) = v;
+                } else {
+                    uint2 h;
+                    h.x = pack2_bf16(v[0], v[1]);
+                    h.y = pack2_bf16(v[2], v[3]);
+                    *(uint2*)(C + o) = h;
+                }
             }
         }
     }
@@ -277,6 +383,8 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
 int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 4 == 0, VITSEG_EINVAL, "gemm_f32: bad M/N/K %d %d %d", a.M,
                      a.N, a.K);
+    VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm: N=%d and ldc=%d must be multiples of 4", a.N,
+                     a.ldc);
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 4 == 0, VITSEG_EINVAL, "gemm_f32: lda %% 4");
         switch (epi) {
@@ -299,8 +407,10 @@ int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s) {
 // bf16 operands (A and W), fp32 accumulate.  Output type follows the consumer: bf16 for tensors
 // that feed the next MFMA (q|k|v, MLP hidden), fp32 for the residual stream and the head features.
 int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
-    VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 8 == 0, VITSEG_EINVAL, "gemm_bf16: bad M/N/K %d %d %d", a.M,
-                     a.N, a.K);
+    VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, VITSEG_EINVAL, "gemm_bf16: bad M/N/K %d %d %d", a.M, a.N, a.K);
+    VITSEG_CHECK_ARG(a.K % 64 == 0, VITSEG_ESHAPE, "gemm_bf16: K=%d must be a multiple of 64", a.K);
+    VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm: N=%d and ldc=%d must be multiples of 4", a.N,
+                     a.ldc);
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 8 == 0, VITSEG_EINVAL, "gemm_bf16: lda %% 8");
         switch (epi) {
@@ -309,7 +419,7 @@ int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
             case EPI_RESADD: return launch_one<bf16_t, float, A_PLAIN, EPI_RESADD>(a, s);
         }
     } else if (amode == A_CONV3 && epi == EPI_RELU) {
-        VITSEG_CHECK_ARG(a.D % 8 == 0, VITSEG_ESHAPE, "hidden size must be a multiple of 8");
+        VITSEG_CHECK_ARG(a.D % 64 == 0 && a.zeros, VITSEG_ESHAPE, "hidden size must be a multiple of 64");
         return launch_one<bf16_t, float, A_CONV3, EPI_RELU>(a, s);
     }
     set_error("gemm_bf16: unsupported amode/epilogue %d/%d", amode, epi);

@@ -30,6 +30,7 @@ struct GemmArgs {
     int lda, ldc;
     // geometry for A_PATCH / A_CONV3 / EPI_POS
     int S, P, g, Np, Cin, D;
+    const void* zeros;  // >= 128 zero bytes (bf16 A_CONV3: source of the padding taps)
 };
 
 int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s);

@@ -133,7 +133,7 @@ inline size_t tensor_offset(const Layout& l, int t, int layer) {
 
 // ---- workspace plan -------------------------------------------------------------
 struct Plan {
-    size_t x, h, qkv, u, f, z, total;  // byte offsets
+    size_t zero, x, h, qkv, u, f, z, total;  // byte offsets
     size_t Mt, Mp;                     // total token rows, patch rows
 };
 
@@ -148,6 +148,7 @@ Plan make_plan(const Shape& s, int B, int precision) {
         off += up(bytes, 256);
         return o;
     };
+    p.zero = take(256);                               // zero page (padding taps of the bf16 3x3 loader)
     p.x = take(p.Mt * s.D * 4);                       // fp32 residual stream
     p.h = take(p.Mt * s.D * 4);                       // LN output / attention context (fp32 sized)
     p.qkv = take(p.Mt * 3 * s.D * act);               // q | k | v
@@ -357,6 +358,11 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         g.A = H; g.W = WG(VITSEG_T_HEAD0_W); g.bias = W(VITSEG_T_HEAD0_B); g.C = F;
         g.M = Mp; g.N = MID; g.K = 9 * D; g.lda = 0; g.ldc = MID;
         g.g = s.g; g.Np = s.Np; g.D = D;
+        g.zeros = ws + p.zero;
+        if (lp) {
+            hipError_t e = hipMemsetAsync(ws + p.zero, 0, 256, st);
+            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(zero page)");
+        }
         {
             ProfScope ps(VITSEG_K_GEMM_CONV3, 2.0 * g.M * g.N * g.K, st);
             rc = lp ? launch_gemm_bf16(g, A_CONV3, EPI_RELU, st) : launch_gemm_f32(g, A_CONV3, EPI_RELU, st);
