@@ -356,10 +356,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
     const int wave = threadIdx.x >> 6;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    // the last (possibly thin) row tile is placed first in the logical order
-    const int tm = t / tiles_n, tile_n = t - tm * tiles_n;
-    const int tile_m = tm == 0 ? tiles_m - 1 : tm - 1;
+    // Logical tile order (each XCD runs a contiguous piece of it, xcd_remap):
+    //  1. a thin last row tile (the CLS rows) goes first;
+    //  2. the rest is walked in column groups of GN tiles, row panels marching inside a group.  The ~64
+    //     blocks resident on an XCD then form an 8x8 patch of tiles (each operand slice shared 8x) and a
+    //     group's W panel (GN*128 rows of K) stays in the 4 MiB L2 while the A panels stream past it.
+    //     (n-fastest order measured 62 % L2 hit rate / 16x over-fetch on the N = 3072 GEMM.)
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int GN = (size_t)p.K * sizeof(T) <= 2048 ? 8 : 4;
+    const bool thin_last = p.M - (tiles_m - 1) * BM <= 64 && tiles_m > 1;
+    int tile_m, tile_n;
+    if (thin_last && t < tiles_n) {
+        tile_m = tiles_m - 1;
+        tile_n = t;
+    } else {
+        const int rows = thin_last ? tiles_m - 1 : tiles_m;
+        if (thin_last) t -= tiles_n;
+        const int gsz = rows * GN, ngroups = (tiles_n + GN - 1) / GN;
+        const int grp = min(t / gsz, ngroups - 1);
+        const int rem = t - grp * gsz;
+        const int gcols = min(GN, tiles_n - grp * GN);
+        tile_m = rem / gcols;
+        tile_n = grp * GN + rem - tile_m * gcols;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int rows_valid = p.M - m0;
     if (rows_valid <= 32)
