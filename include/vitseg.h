@@ -138,6 +138,15 @@ int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patc
 int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask, int batch, int C, int g, int S,
                               void* stream);
 
+/* ---- loss (replaces nn.CrossEntropyLoss()(logits, y), classes.py:268,280) ----
+ * lowres: fp32 [B, C, g, g] low-resolution logits (VITSEG_BUF_LOWRES after vitseg_forward); target: class
+ * indices [B, S, S], int64 (torch.long, as the reference passes them) or uint8.  Writes the mean loss to
+ * *loss (device fp32).  scratch: >= vitseg_ce_scratch_bytes() device bytes.  grad_logits (optional, fp32
+ * [B, C, S, S]) receives d loss / d logits. */
+size_t vitseg_ce_scratch_bytes(int batch, int S);
+int vitseg_ce_loss(const float* lowres, const void* target, int target_is_u8, float* grad_logits, void* scratch,
+                   float* loss, int batch, int C, int g, int S, void* stream);
+
 /* ---- measurement hooks (bench.py's roofline object) ----
  * While enabled, vitseg_forward brackets every kernel launch of the hot path with a pair of
  * hipEvents on the launch stream.  vitseg_profile_collect synchronises those events (the only

@@ -103,3 +103,30 @@ def test_forward_bf16_close_to_golden(name):
     mism = (mask.cpu().numpy() != ref).mean()
     print(f"{name}: bf16 logits max-abs err {err:.3e}, mask mismatch rate {mism:.4%}")
     assert mism < 0.05
+
+
+@pytest.mark.parametrize("name", ["tiny16_224_c2", "base16w_l2_224_c2_train"])
+def test_ce_loss_matches_reference(name):
+    """LightningViTModel.validation_step: nearest-resized targets + CE, against the reference's loss value."""
+    from visiontransformer_amd.lightning import LightningViTModel
+    g = Golden(name)
+    c = g.cfg
+    lm = LightningViTModel(c.num_classes, c.patch_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
+                           image_size=c.image_size, device=DEV).eval()
+    lm.load_state_dict({"model." + k: v for k, v in g.state_dict().items()})
+    y = g.targets().to(DEV)
+    assert np.array_equal(lm._resize_target(y, (c.image_size,) * 2).cpu().numpy().astype(np.uint8),
+                          g.z["train.target_resized"])
+    loss = lm.validation_step((g.images().to(DEV), y), 0)
+    assert abs(float(loss) - float(g.z["train.loss"][0])) < 2e-6
+    assert abs(lm.logged["valid_loss"] - float(g.z["train.loss"][0])) < 2e-6
+    # 17-class targets as uint8 against the oracle
+    cfg = ViTSegConfig(5, 16, 192, 1, 3, image_size=112)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=8).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 2, seed=2))
+    t = torch.from_numpy(synth.make_targets(cfg, 2, seed=2, size=112))
+    m = ViTSegmentationModel(5, 16, 192, 1, 3, image_size=112, device=DEV).eval()
+    m.load_state_dict(sd)
+    ref = O.ce_loss(O.forward(x.double(), {k: v.double() for k, v in sd.items()}, cfg), t)
+    got = m.ce_loss(x.to(DEV), t.to(torch.uint8).to(DEV))
+    assert abs(float(got) - float(ref)) < 5e-6

@@ -26,6 +26,7 @@ EXPORTS = [
     "vitseg_query_workspace", "vitseg_workspace_offset", "vitseg_forward", "vitseg_op_layernorm_f32",
     "vitseg_op_linear_f32", "vitseg_op_attention_f32", "vitseg_op_upsample_argmax",
     "vitseg_profile_enable", "vitseg_profile_collect", "vitseg_op_linear_bf16", "vitseg_op_attention_bf16",
+    "vitseg_ce_scratch_bytes", "vitseg_ce_loss",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
                 "head1x1", "upsample"]
@@ -70,6 +71,9 @@ def lib() -> C.CDLL:
         l.vitseg_op_linear_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_upsample_argmax.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+        l.vitseg_ce_scratch_bytes.argtypes = [i32, i32]
+        l.vitseg_ce_scratch_bytes.restype = sz
+        l.vitseg_ce_loss.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_profile_enable.argtypes = [i32]
         l.vitseg_profile_collect.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         for name in EXPORTS:

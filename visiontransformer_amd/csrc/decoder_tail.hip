@@ -95,7 +95,93 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     }
 }
 
+// nn.CrossEntropyLoss() on the upsampled logits (model/CE/classes.py:268,280): mean over B*S*S pixels of
+// logsumexp_c(logit) - logit[target].  The logits are re-generated from the low-res map (same exact
+// bilinear arithmetic as upsample_kernel) instead of being read back from HBM, so the loss costs one
+// pass over the targets.  Optionally writes G = d loss / d logits = (softmax - onehot) / (B*S*S)
+// (fp32 [B, C, S, S]) for the backward pass.  Deterministic: per-block partial sums in fp64, reduced in a
+// fixed order by ce_finish_kernel.
+template <typename TargetT>
+__global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ Z, const TargetT* __restrict__ target,
+                                                      float* __restrict__ G, double* __restrict__ partial, int B, int C,
+                                                      int g, int S) {
+    __shared__ double red[4];
+    const size_t npx = (size_t)B * S * S;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double local = 0.0;
+    if (idx < npx) {
+        const int X = (int)(idx % S), Y = (int)((idx / S) % S), b = (int)(idx / ((size_t)S * S));
+        const float scale = (float)g / (float)S;
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        taps(Y, scale, g, y0, y1, wy0, wy1);
+        taps(X, scale, g, x0, x1, wx0, wx1);
+        const int t = (int)target[idx];
+        auto logit = [&](int c) {
+            const float* zt = Z + (((size_t)b * C + c) * g + y0) * g;
+            const float* zb = Z + (((size_t)b * C + c) * g + y1) * g;
+            const float top = __fmaf_rn(zt[x0], wx0, __fmul_rn(zt[x1], wx1));
+            const float bot = __fmaf_rn(zb[x0], wx0, __fmul_rn(zb[x1], wx1));
+            return __fmaf_rn(top, wy0, __fmul_rn(bot, wy1));
+        };
+        float m = -INFINITY, ssum = 0.f, picked = 0.f;
+        for (int c = 0; c < C; ++c) {  // online logsumexp
+            const float v = logit(c);
+            if (c == t) picked = v;
+            const float mn = fmaxf(m, v);
+            ssum = ssum * expf(m - mn) + expf(v - mn);
+            m = mn;
+        }
+        const float lse = m + logf(ssum);
+        local = (double)(lse - picked);
+        if (G) {
+            const float inv = 1.0f / (float)npx;
+            for (int c = 0; c < C; ++c) {
+                const float pc = expf(logit(c) - lse);
+                G[(((size_t)b * C + c) * S + Y) * S + X] = (pc - (c == t ? 1.f : 0.f)) * inv;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void ce_finish_kernel(const double* __restrict__ partial, int n, double inv_count,
+                                                        float* __restrict__ loss) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];  // fixed order per thread
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * inv_count);
+}
+
 }  // namespace
+
+size_t ce_partial_count(int B, int S) { return ((size_t)B * S * S + 255) / 256; }
+
+int launch_ce_loss(const float* Z, const void* target, int target_is_u8, float* G, double* partial, float* loss, int B,
+                   int C, int g, int S, hipStream_t s) {
+    VITSEG_CHECK_ARG(Z && target && partial && loss, VITSEG_EINVAL, "ce_loss: null pointer");
+    const unsigned nb = (unsigned)ce_partial_count(B, S);
+    if (target_is_u8)
+        hipLaunchKernelGGL(ce_loss_kernel<uint8_t>, dim3(nb), dim3(256), 0, s, Z, (const uint8_t*)target, G, partial, B,
+                           C, g, S);
+    else
+        hipLaunchKernelGGL(ce_loss_kernel<long long>, dim3(nb), dim3(256), 0, s, Z, (const long long*)target, G,
+                           partial, B, C, g, S);
+    VITSEG_LAUNCH_CHECK("ce_loss");
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, partial, (int)nb, 1.0 / ((double)B * S * S), loss);
+    VITSEG_LAUNCH_CHECK("ce_finish");
+    return VITSEG_OK;
+}
 
 int launch_head1x1(const float* F, const float* W2, const float* b2, float* Z, int B, int Np, int C, hipStream_t s) {
     VITSEG_CHECK_ARG(F && W2 && b2 && Z, VITSEG_EINVAL, "head1x1: null pointer");

@@ -378,6 +378,15 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     return launch_upsample(Z, logits, mask, batch, s.C, s.g, s.S, st);
 }
 
+size_t vitseg_ce_scratch_bytes(int batch, int S) { return ce_partial_count(batch, S) * sizeof(double); }
+
+int vitseg_ce_loss(const float* lowres, const void* target, int target_is_u8, float* grad_logits, void* scratch,
+                   float* loss, int batch, int C, int g, int S, void* stream) {
+    VITSEG_CHECK_ARG(batch >= 1 && C >= 1 && g >= 1 && S >= g, VITSEG_EINVAL, "ce_loss: bad shape");
+    return launch_ce_loss(lowres, target, target_is_u8, grad_logits, (double*)scratch, loss, batch, C, g, S,
+                          (hipStream_t)stream);
+}
+
 int vitseg_profile_enable(int on) {
     g_prof.clear();
     g_prof.on = on != 0;

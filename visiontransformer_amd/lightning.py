@@ -1,0 +1,59 @@
+"""`LightningViTModel` -- the CE training/eval module of the reference without the `lightning`
+dependency (/root/reference/model/CE/classes.py:264-297).
+
+Same constructor, `forward`, `_resize_target`, `training_step`, `validation_step`,
+`configure_optimizers` (Adam lr=1e-5), and the same checkpoint layout: `state_dict()` keys carry the
+`model.` prefix of the reference's attribute name (classes.py:267) and `load_state_dict` accepts
+`torch.load(ckpt)['state_dict']` as written by Lightning (model/CE/testViTModel.py:117-118).
+Logging (`self.log`) is replaced by a plain `logged` dict; a minimal trainer loop lives in
+`visiontransformer_amd.trainer`.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .model import ViTSegmentationModel
+
+
+class LightningViTModel(nn.Module):
+    def __init__(self, num_classes, patch_size, hidden_size, num_hidden_layers, num_attention_heads, **kw):
+        super().__init__()
+        self.model = ViTSegmentationModel(num_classes, patch_size, hidden_size, num_hidden_layers,
+                                          num_attention_heads, **kw)
+        self.logged = {}
+
+    def forward(self, x):
+        return self.model(x)
+
+    def _resize_target(self, y, size):
+        # classes.py:273-274 (host-side label preprocessing; nearest: idx = min(floor(dst*in/out), in-1))
+        return F.interpolate(y.unsqueeze(1).float(), size=size, mode="nearest").squeeze(1).long()
+
+    def _loss(self, batch):
+        x, y = batch
+        S = self.model.cfg.image_size  # the reference hard-codes (224, 224) = its image_size (classes.py:278)
+        y = self._resize_target(y, size=(S, S))
+        return self.model.ce_loss(x, y)
+
+    def training_step(self, batch, batch_idx):
+        loss = self._loss(batch)
+        self.logged["train_loss"] = float(loss.detach())
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        with torch.no_grad():
+            loss = self._loss(batch)
+        self.logged["valid_loss"] = float(loss)
+        return loss
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=1e-5)  # classes.py:296-297
+
+    # checkpoint schema: every key prefixed with "model." like the reference module tree
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        return self.model.state_dict(destination=destination, prefix=prefix + "model.", keep_vars=keep_vars)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        return self.model.load_state_dict(state_dict, strict=strict)

@@ -179,6 +179,26 @@ class ViTSegmentationModel(nn.Module):
         logits, mask = self._run(x, return_logits, True)
         return (mask, logits) if return_logits else mask
 
+    def ce_loss(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """`nn.CrossEntropyLoss()(self(x), target)` (model/CE/classes.py:268,280) as a device scalar, without
+        materialising the [B, C, S, S] logits: forward to the low-res map, then the fused upsample+CE kernel.
+        `target`: class indices [B, S, S], torch.long (reference) or torch.uint8, on the model's device."""
+        if torch.is_grad_enabled() and self.arena.requires_grad and self.training:
+            raise NotImplementedError("the backward pass through libvitseg is not built yet; use torch.no_grad()")
+        S, B = self.cfg.image_size, x.shape[0]
+        if tuple(target.shape) != (B, S, S) or target.dtype not in (torch.int64, torch.uint8):
+            raise ValueError(f"target must be int64/uint8 [B, {S}, {S}], got {target.dtype} {tuple(target.shape)}")
+        with torch.no_grad():
+            _, _ = self._run(x, False, True)  # fills the low-res logits (mask output is a by-product)
+            low = self.debug_buffer(B, _lib.BUF_LOWRES)
+            target = target.to(self.arena.device).contiguous()
+            scratch = torch.empty(_lib.lib().vitseg_ce_scratch_bytes(B, S), dtype=torch.uint8, device=low.device)
+            loss = torch.empty((), dtype=torch.float32, device=low.device)
+            _lib.check(_lib.lib().vitseg_ce_loss(low.data_ptr(), target.data_ptr(), int(target.dtype == torch.uint8),
+                                                 None, scratch.data_ptr(), loss.data_ptr(), B, self.cfg.num_classes,
+                                                 self.cfg.grid, S, torch.cuda.current_stream().cuda_stream))
+        return loss
+
     @torch.no_grad()
     def debug_buffer(self, batch: int, which: int) -> torch.Tensor:
         """fp32 view of a workspace buffer defined after forward (parity tests)."""
