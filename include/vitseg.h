@@ -147,6 +147,34 @@ size_t vitseg_ce_scratch_bytes(int batch, int S);
 int vitseg_ce_loss(const float* lowres, const void* target, int target_is_u8, float* grad_logits, void* scratch,
                    float* loss, int batch, int C, int g, int S, void* stream);
 
+/* ---- training (replaces autograd behind LightningViTModel.training_step, classes.py:276-285, and
+ *      torch.optim.Adam(lr=1e-5).step(), classes.py:296-297).  VITSEG_F32 only in this build; dropout p = 0.
+ * vitseg_forward_train saves every activation the backward needs inside `workspace`
+ * (vitseg_train_workspace bytes; it must stay untouched until vitseg_backward has run) and optionally
+ * writes the fp32 logits.  vitseg_backward takes EITHER integer targets (fused CE: writes the mean loss to
+ * *loss) OR the gradient of an arbitrary loss w.r.t. the logits (fp32 [B, C, S, S]) and fills `grads`, an
+ * arena-shaped fp32 buffer (same offsets as the parameters). */
+int vitseg_train_workspace(const vitseg_config* cfg, int batch, int precision, size_t* bytes);
+int vitseg_forward_train(const vitseg_config* cfg, const float* params, const float* x, int batch, int precision,
+                         float* logits, void* workspace, size_t workspace_bytes, void* stream);
+int vitseg_backward(const vitseg_config* cfg, const float* params, const float* x, int batch, int precision,
+                    const void* target, int target_is_u8, const float* grad_logits, float* grads, float* loss,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* one Adam step over a flat fp32 buffer (torch.optim.Adam semantics, weight_decay 0, amsgrad off);
+ * step is 1-based; gradients are multiplied by grad_scale first (1/world for summed all-reduce). */
+int vitseg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n_floats, float lr,
+                     float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* fp32 GEMM with explicit operand forms, exported for the parity tests of the backward GEMMs:
+ * C[M,N] = A . W with A N-form [M][K] (ta = 0) or T-form [K][M] (ta = 1), W N-form [N][K] (tb = 0) or
+ * T-form [K][N] (tb = 1); epilogue 0 = plain, 5 = multiply by gelu'(R[M,N]). */
+int vitseg_op_gemm_f32(const float* A, const float* W, const float* R, float* C, int M, int N, int K, int ta, int tb,
+                       int epilogue, void* stream);
+int vitseg_op_attention_bwd_f32(const float* qkv, const float* dctx, float* ctx_out, float* lse_out, float* scratch,
+                                float* dqkv, int batch, int num_patches, int num_heads, void* stream);
+int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out,
+                                float* dw, float* db, float* scratch, int rows, int D, float eps, void* stream);
+
 /* ---- measurement hooks (bench.py's roofline object) ----
  * While enabled, vitseg_forward brackets every kernel launch of the hot path with a pair of
  * hipEvents on the launch stream.  vitseg_profile_collect synchronises those events (the only

@@ -1,0 +1,137 @@
+"""GPU (-m gpu): backward kernels and the training step, through the C ABI, against the oracle
+(autograd on the CPU restatement) and the golden gradients of the real reference class."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitseg_oracle as O
+from util import CASES, Golden
+from visiontransformer_amd import _lib, synth
+from visiontransformer_amd.config import ViTSegConfig
+from visiontransformer_amd.lightning import LightningViTModel
+from visiontransformer_amd.model import ViTSegmentationModel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,epi", [
+    (257, 192, 96, 0, 1, 0), (1025, 768, 2304, 0, 1, 0), (300, 3072, 768, 0, 1, 5),
+    (192, 576, 1025, 1, 1, 0), (768, 3072, 2050, 1, 1, 0), (256, 6912, 300, 1, 1, 0), (64, 100, 37, 1, 1, 0)])
+def test_gemm_operand_forms(M, N, K, ta, tb, epi):
+    A = _rand(K, M, seed=1) if ta else _rand(M, K, seed=1)
+    W = _rand(K, N, seed=2, scale=0.05) if tb else _rand(N, K, seed=2, scale=0.05)
+    R = _rand(M, N, seed=3)
+    a64 = A.double().T if ta else A.double()
+    w64 = W.double() if tb else W.double().T
+    ref = a64 @ w64
+    if epi == 5:
+        u = R.double()
+        ref = ref * (0.5 * (1 + torch.erf(u / 2 ** 0.5)) + u * torch.exp(-0.5 * u * u) / (2 * np.pi) ** 0.5)
+    Ad, Wd, Rd = A.to(DEV), W.to(DEV), R.to(DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_gemm_f32(Ad.data_ptr(), Wd.data_ptr(), Rd.data_ptr(), C.data_ptr(), M, N, K, ta, tb,
+                                             epi, _stream()))
+    bound = 4e-7 * (a64.abs() @ w64.abs()).max().item() + 1e-6
+    assert (C.cpu().double() - ref).abs().max().item() < bound
+
+
+@pytest.mark.parametrize("rows,D", [(7, 192), (1025, 768), (130, 1024), (64, 512)])
+def test_layernorm_backward(rows, D):
+    x = (_rand(rows, D, seed=1, scale=2.0) + 0.3).double().requires_grad_(True)
+    w = (_rand(D, seed=2) + 1.0).double().requires_grad_(True)
+    b = _rand(D, seed=3).double().requires_grad_(True)
+    g, dres = _rand(rows, D, seed=4), _rand(rows, D, seed=5)
+    y = O.layer_norm(x, w, b, 1e-12)
+    y.backward(g.double())
+    xd, wd, gd, rd = x.detach().float().to(DEV), w.detach().float().to(DEV), g.to(DEV), dres.to(DEV)
+    out, dw, db = torch.empty(rows, D, device=DEV), torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    scratch = torch.empty(((rows + 63) // 64) * 2 * D, device=DEV)
+    _lib.check(_lib.lib().vitseg_op_layernorm_bwd_f32(xd.data_ptr(), wd.data_ptr(), gd.data_ptr(), rd.data_ptr(),
+                                                      out.data_ptr(), dw.data_ptr(), db.data_ptr(), scratch.data_ptr(),
+                                                      rows, D, 1e-12, _stream()))
+    assert (out.cpu().double() - (dres.double() + x.grad)).abs().max().item() < 2e-5
+    assert (dw.cpu().double() - w.grad).abs().max().item() < 1e-5 * max(1.0, w.grad.abs().max().item())
+    assert (db.cpu().double() - b.grad).abs().max().item() < 1e-5 * max(1.0, b.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("B,Np,A", [(2, 196, 3), (1, 1024, 2), (1, 64, 1), (2, 100, 2)])
+def test_attention_backward(B, Np, A):
+    D, Mt = 64 * A, B * Np + B
+    qkv = _rand(Mt, 3 * D, seed=Np + A, scale=1.2)
+    dctx = _rand(Mt, D, seed=9)
+    x = qkv.double().requires_grad_(True)
+    outs = []
+    for b in range(B):
+        r = torch.cat([torch.tensor([B * Np + b]), torch.arange(b * Np, (b + 1) * Np)])
+        q, k, v = [x[r][:, i * D:(i + 1) * D].reshape(Np + 1, A, 64).transpose(0, 1) for i in range(3)]
+        s = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+        outs.append(((s @ v).transpose(0, 1).reshape(Np + 1, D) * dctx.double()[r]).sum())
+    torch.stack(outs).sum().backward()
+    qd, dd = qkv.to(DEV), dctx.to(DEV)
+    ctx = torch.empty(Mt, D, device=DEV)
+    lse = torch.empty(B * A * (Np + 1), device=DEV)
+    scr = torch.empty(B * A * (Np + 1), device=DEV)
+    dqkv = torch.full((Mt, 3 * D), float("nan"), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_attention_bwd_f32(qd.data_ptr(), dd.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
+                                                      scr.data_ptr(), dqkv.data_ptr(), B, Np, A, _stream()))
+    err = (dqkv.cpu().double() - x.grad).abs().max().item()
+    assert err < 5e-5 * max(1.0, x.grad.abs().max().item()), err
+
+
+def _build(g: Golden):
+    c = g.cfg
+    lm = LightningViTModel(c.num_classes, c.patch_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
+                           image_size=c.image_size, device=DEV)
+    lm.load_state_dict({"model." + k: v for k, v in g.state_dict().items()})
+    return lm
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if Golden(c).has("grad.seg_head.2.weight")])
+def test_training_step_matches_reference_gradients(name):
+    """LightningViTModel.training_step + backward + one Adam(lr=1e-5) step vs the real reference class."""
+    g = Golden(name)
+    lm = _build(g).train()
+    opt = lm.configure_optimizers()
+    loss = lm.training_step((g.images().to(DEV), g.targets().to(DEV)), 0)
+    assert abs(float(loss) - float(g.z["train.loss"][0])) < 2e-6
+    loss.backward()
+    views = {k: v for k, v in zip(lm.model.named_views().keys(),
+                                  __import__("visiontransformer_amd.params", fromlist=["x"]).arena_views(
+                                      g.cfg, lm.model.arena.grad).values())}
+    for key in [k[5:-4] for k in g.z.files if k.startswith("grad.") and k.endswith(".idx")]:
+        err, scale = g.max_abs_err("grad." + key, views[key])
+        assert err <= 5e-4 * scale + 1e-9, (key, err, scale)
+    before = {k: v.clone() for k, v in lm.model.named_views().items()}
+    opt.step()
+    after = lm.model.named_views()
+    for key in [k[6:-4] for k in g.z.files if k.startswith("adam1.") and k.endswith(".idx")]:
+        err, _ = g.max_abs_err("adam1." + key, after[key] - before[key])
+        assert err <= 2.1e-5, (key, err)  # a sign flip of a ~0 gradient moves the first Adam update by 2*lr
+
+
+def test_logits_autograd_matches_oracle():
+    """Arbitrary loss on the logits (the PAED losses' route): d loss / d arena through vitseg_backward."""
+    cfg = ViTSegConfig(3, 16, 192, 2, 3, image_size=96)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=31).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 2, seed=4))
+    wgt = _rand(2, 3, 96, 96, seed=6)
+    leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    (O.forward(x.double(), leaf, cfg) * wgt.double()).sum().backward()
+    m = ViTSegmentationModel(3, 16, 192, 2, 3, image_size=96, device=DEV).train()
+    m.load_state_dict(sd)
+    (m(x.to(DEV)) * wgt.to(DEV)).sum().backward()
+    from visiontransformer_amd.params import arena_views
+    gv = arena_views(cfg, m.arena.grad)
+    for k, ref in leaf.items():
+        err = (gv[k].cpu().double() - ref.grad).abs().max().item()
+        assert err <= 2e-4 * max(ref.grad.abs().max().item(), 1e-3), (k, err, ref.grad.abs().max().item())

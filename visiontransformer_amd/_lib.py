@@ -27,6 +27,8 @@ EXPORTS = [
     "vitseg_op_linear_f32", "vitseg_op_attention_f32", "vitseg_op_upsample_argmax",
     "vitseg_profile_enable", "vitseg_profile_collect", "vitseg_op_linear_bf16", "vitseg_op_attention_bf16",
     "vitseg_ce_scratch_bytes", "vitseg_ce_loss",
+    "vitseg_train_workspace", "vitseg_forward_train", "vitseg_backward", "vitseg_adam_step",
+    "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
                 "head1x1", "upsample"]
@@ -74,6 +76,14 @@ def lib() -> C.CDLL:
         l.vitseg_ce_scratch_bytes.argtypes = [i32, i32]
         l.vitseg_ce_scratch_bytes.restype = sz
         l.vitseg_ce_loss.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]
+        f32 = C.c_float
+        l.vitseg_train_workspace.argtypes = [pcfg, i32, i32, psz]
+        l.vitseg_forward_train.argtypes = [pcfg, vp, vp, i32, i32, vp, vp, sz, vp]
+        l.vitseg_backward.argtypes = [pcfg, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+        l.vitseg_adam_step.argtypes = [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, f32, vp]
+        l.vitseg_op_gemm_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+        l.vitseg_op_attention_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+        l.vitseg_op_layernorm_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]
         l.vitseg_profile_enable.argtypes = [i32]
         l.vitseg_profile_collect.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         for name in EXPORTS:
@@ -116,6 +126,12 @@ def workspace_offset(cfg: ViTSegConfig, batch: int, precision: int, buffer: int)
     check(lib().vitseg_workspace_offset(C.byref(CConfig.from_config(cfg)), batch, precision, buffer,
                                         C.byref(off), C.byref(n)))
     return off.value, n.value
+
+
+def train_workspace(cfg: ViTSegConfig, batch: int, precision: int) -> int:
+    n = C.c_size_t()
+    check(lib().vitseg_train_workspace(C.byref(CConfig.from_config(cfg)), batch, precision, C.byref(n)))
+    return n.value
 
 
 def profile_enable(on: bool) -> None:

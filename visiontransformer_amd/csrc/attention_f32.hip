@@ -34,7 +34,7 @@ __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 
 
 template <bool RAGGED>
 __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
-                                                          int B, int Np, int A) {
+                                                          float* __restrict__ lse, int B, int Np, int A) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][KB * HD];  // [buffer][K|V][key*64 + d], 64 KiB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,6 +183,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
     // ---- normalise and store: lane holds d = dt*32 + 8 g4 + 4 lh + e of its query ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    // log-sum-exp of the scaled scores in log2 units, [b][head][token] with the CLS token last (backward)
+    if (lse && q_valid && lh == 0) lse[((size_t)b * A + head) * (Np + 1) + q_local] = m_run + __builtin_amdgcn_logf(l_tot);
     if (q_valid) {
         float* out = ctx + q_row * (size_t)D + head * HD;
 #pragma unroll
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
 
 // The B*A CLS queries: one block per (head, image); plain VALU (1 x N x 64 per block).
 __global__ __launch_bounds__(256) void attn_cls_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
-                                                           int B, int Np, int A) {
+                                                           float* __restrict__ lse, int B, int Np, int A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // scores[N] then reduce scratch
     const int N = Np + 1;
     float* sc = sm;
@@ -247,7 +249,9 @@ __global__ __launch_bounds__(256) void attn_cls_f32_kernel(const float* __restri
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
-    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    const float ltot = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / ltot;
+    if (lse && tid == 0) lse[((size_t)b * A + head) * N + Np] = mx + __builtin_amdgcn_logf(ltot);
     __syncthreads();
     // out[d] = sum_key p[key] V[key][d]: thread = (key group kg of 16, 4-float chunk sub)
     const int kg = tid >> 4;
@@ -269,17 +273,17 @@ __global__ __launch_bounds__(256) void attn_cls_f32_kernel(const float* __restri
 
 }  // namespace
 
-int launch_attention_f32(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s) {
+int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_f32: bad arguments");
     const dim3 grid((Np + QB - 1) / QB, A, B);
     if (Np % QB == 0)
-        hipLaunchKernelGGL(attn_f32_kernel<false>, grid, dim3(256), 0, s, qkv, ctx, B, Np, A);
+        hipLaunchKernelGGL(attn_f32_kernel<false>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A);
     else
-        hipLaunchKernelGGL(attn_f32_kernel<true>, grid, dim3(256), 0, s, qkv, ctx, B, Np, A);
+        hipLaunchKernelGGL(attn_f32_kernel<true>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A);
     VITSEG_LAUNCH_CHECK("attn_f32");
     const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 16 * 64) * sizeof(float);
     VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_f32: sequence too long for the CLS kernel");
-    hipLaunchKernelGGL(attn_cls_f32_kernel, dim3(A, B), dim3(256), smem, s, qkv, ctx, B, Np, A);
+    hipLaunchKernelGGL(attn_cls_f32_kernel, dim3(A, B), dim3(256), smem, s, qkv, ctx, lse, B, Np, A);
     VITSEG_LAUNCH_CHECK("attn_cls_f32");
     return VITSEG_OK;
 }

@@ -1,0 +1,393 @@
+// Backward-pass kernels that are not GEMMs or attention (a13: what autograd runs behind
+// LightningViTModel.training_step, /root/reference/model/CE/classes.py:276-285, and Adam, :296-297).
+// All reductions are deterministic: per-block partial sums in a scratch buffer, finished in a fixed order.
+#include "kernels.hpp"
+
+namespace vitseg {
+namespace {
+
+constexpr int MID = 256;
+
+// ---- column sums: out[n] = sum_m X[m][n]  (bias gradients) -----------------------------------
+// stage 1: block = 256 columns x a chunk of 256 rows -> partial[chunk][n]; stage 2: sum the chunks.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, float* __restrict__ partial,
+                                                             int M, int N, int ld) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * 256, r1 = min(r0 + 256, M);
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += X[(size_t)r * ld + n];
+    partial[(size_t)blockIdx.y * N + n] = s;
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int chunks, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * N + n];
+    out[n] = s;
+}
+
+// ---- LayerNorm backward ------------------------------------------------------------------------
+// y = xhat * w + b, xhat = (x - mu) * rstd.  With gw = g * w:
+//   dx = rstd * (gw - mean(gw) - xhat * mean(gw * xhat));   dw = sum_rows g * xhat;   db = sum_rows g.
+// dres_out[row] = (dres_in ? dres_in[row] : 0) + dx  (the residual branch's gradient is added here).
+// One wave per row (statistics recomputed from the saved input), 64 rows per block; the block's dw/db
+// partial sums go to partial[block][2][D].
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ g, const float* dres_in,
+                                                            float* dres_out, float* __restrict__ partial, int rows,
+                                                            int D, float eps) {
+    __shared__ float red[2][4][NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 2;
+    f32x4 wv[NV], dw[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        wv[i] = ((const f32x4*)w)[min(lane + 64 * i, nv - 1)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dw[i][e] = db[i][e] = 0.f;
+    }
+    for (int it = 0; it < 16; ++it) {
+        const int row = blockIdx.x * 64 + it * 4 + wave;
+        if (row >= rows) break;  // wave-uniform
+        f32x4 xv[NV], gv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = min(lane + 64 * i, nv - 1);
+            xv[i] = ((const f32x4*)(x + (size_t)row * D))[c];
+            gv[i] = ((const f32x4*)(g + (size_t)row * D))[c];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float t = (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+            s += (lane + 64 * i < nv) ? t : 0.f;
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[i][e] -= mean;
+                t = fmaf(xv[i][e], xv[i][e], t);
+            }
+            q += (lane + 64 * i < nv) ? t : 0.f;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bool ok = lane + 64 * i < nv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[i][e] *= rstd;  // xhat
+                const float gw = gv[i][e] * wv[i][e];
+                if (ok) {
+                    s1 += gw;
+                    s2 = fmaf(gw, xv[i][e], s2);
+                    dw[i][e] = fmaf(gv[i][e], xv[i][e], dw[i][e]);
+                    db[i][e] += gv[i][e];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (dres_in) o = ((const f32x4*)(dres_in + (size_t)row * D))[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += rstd * (gv[i][e] * wv[i][e] - c1 - xv[i][e] * c2);
+                ((f32x4*)(dres_out + (size_t)row * D))[c] = o;
+            }
+        }
+    }
+    // block reduction of dw / db over the 4 waves, fixed order
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[0][wave][(lane + 64 * i) * 4 + e] = dw[i][e];
+            red[1][wave][(lane + 64 * i) * 4 + e] = db[i][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        partial[((size_t)blockIdx.x * 2 + 0) * D + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        partial[((size_t)blockIdx.x * 2 + 1) * D + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+}
+// partial[block][2][D] -> dw[D], db[D]
+__global__ __launch_bounds__(256) void layernorm_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                   float* __restrict__ db, int blocks, int D) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < blocks; ++k) {
+        a += partial[((size_t)k * 2 + 0) * D + c];
+        b += partial[((size_t)k * 2 + 1) * D + c];
+    }
+    dw[c] = a;
+    db[c] = b;
+}
+
+// ---- transposed bilinear upsample: G[B,C,S,S] -> dZ[B,C,g,g] -----------------------------------
+// Gather form of the adjoint of upsample_kernel: cell (y, x) collects every output pixel that has it as a
+// tap, with the same tap arithmetic as the forward.  One wave per low-res cell; deterministic.
+__device__ __forceinline__ void taps_bwd(int d, float scale, int n_in, int& i0, int& i1, float& w0, float& w1) {
+    float src = scale * ((float)d + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = min((int)floorf(src), n_in - 1);
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    w1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+    w0 = 1.f - w1;
+}
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ G, float* __restrict__ dZ, int B,
+                                                           int C, int g, int S) {
+    const int lane = threadIdx.x & 63;
+    const size_t cell = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= (size_t)B * C * g * g) return;
+    const int x = (int)(cell % g), y = (int)((cell / g) % g);
+    const size_t bc = cell / ((size_t)g * g);
+    const int P = S / g;
+    const float scale = (float)g / (float)S;
+    const int Y0 = max(0, (y - 1) * P), Y1 = min(S, (y + 2) * P);
+    const int X0 = max(0, (x - 1) * P), X1 = min(S, (x + 2) * P);
+    const float* Gp = G + bc * (size_t)S * S;
+    float acc = 0.f;
+    for (int X = X0 + lane; X < X1; X += 64) {
+        int i0, i1;
+        float w0, w1;
+        taps_bwd(X, scale, g, i0, i1, w0, w1);
+        const float wx = (i0 == x ? w0 : 0.f) + (i1 == x ? w1 : 0.f);
+        if (wx == 0.f) continue;
+        float col = 0.f;
+        for (int Y = Y0; Y < Y1; ++Y) {
+            taps_bwd(Y, scale, g, i0, i1, w0, w1);
+            const float wy = (i0 == y ? w0 : 0.f) + (i1 == y ? w1 : 0.f);
+            col = fmaf(wy, Gp[(size_t)Y * S + X], col);
+        }
+        acc = fmaf(wx, col, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dZ[cell] = acc;
+}
+
+// ---- seg_head.2 (1x1 conv) backward + ReLU backward --------------------------------------------
+// dFpre[m][j] = (F[m][j] > 0) * sum_c dZ[b,c,t] W2[c][j];  dW2[c][j] = sum_m dZ[b,c,t] F[m][j].
+// Thread = mid channel j, block = 64 rows; partial dW2 to partial[block][C][256].  C <= 32.
+__global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float* __restrict__ dZ, const float* __restrict__ F,
+                                                          const float* __restrict__ W2, float* __restrict__ dFpre,
+                                                          float* __restrict__ partial, int B, int Np, int C) {
+    const int j = threadIdx.x;
+    float w[32], dw[32];
+    for (int c = 0; c < C; ++c) {
+        w[c] = W2[c * MID + j];
+        dw[c] = 0.f;
+    }
+    const int M = B * Np;
+    for (int it = 0; it < 64; ++it) {
+        const int m = blockIdx.x * 64 + it;
+        if (m >= M) break;
+        const int b = m / Np, t = m - b * Np;
+        const float f = F[(size_t)m * MID + j];
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float dz = dZ[((size_t)b * C + c) * Np + t];
+            s = fmaf(dz, w[c], s);
+            dw[c] = fmaf(dz, f, dw[c]);
+        }
+        dFpre[(size_t)m * MID + j] = f > 0.f ? s : 0.f;
+    }
+    for (int c = 0; c < C; ++c) partial[((size_t)blockIdx.x * C + c) * MID + j] = dw[c];
+}
+// db2[c] = sum over (b, t) of dZ[b,c,t]; one block per class
+__global__ __launch_bounds__(256) void head_bias_bwd_kernel(const float* __restrict__ dZ, float* __restrict__ db2, int B,
+                                                            int Np, int C) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B * Np; i += 256) {
+        const int b = i / Np, t = i - b * Np;
+        s += dZ[((size_t)b * C + c) * Np + t];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db2[c] = red[0];
+}
+
+// ---- im2col materialisation for the two conv weight gradients (T-form B operands of the wgrad GEMM) ----
+// 3x3, pad 1 on the token-major map: T[m][tap*D + d] = H[(b, y+ky-1, x+kx-1)][d] or 0
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ H, float* __restrict__ T, int B, int g,
+                                                        int D) {
+    const int nv = D >> 2;
+    const size_t total = (size_t)B * g * g * 9 * nv;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int dv = (int)(i % nv);
+        const int tap = (int)((i / nv) % 9);
+        const size_t m = i / ((size_t)nv * 9);
+        const int x = (int)(m % g), y = (int)((m / g) % g);
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)yy < (unsigned)g && (unsigned)xx < (unsigned)g)
+            v = ((const f32x4*)(H + (m + (ptrdiff_t)(yy - y) * g + (xx - x)) * D))[dv];
+        ((f32x4*)T)[i] = v;
+    }
+}
+// patch rows of the NCHW image: T[m][(c, py, px)]
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, float* __restrict__ T, int B,
+                                                           int Cin, int S, int P) {
+    const int g = S / P, Kp = Cin * P * P, nv = Kp >> 2;
+    const size_t total = (size_t)B * g * g * nv;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int kv = (int)(i % nv);
+        const size_t m = i / nv;
+        const int gx = (int)(m % g), gy = (int)((m / g) % g), b = (int)(m / ((size_t)g * g));
+        const int k = kv * 4, c = k / (P * P), rem = k - c * P * P, py = rem / P, px = rem - py * P;
+        ((f32x4*)T)[i] = *(const f32x4*)(img + (((size_t)b * Cin + c) * S + gy * P + py) * S + gx * P + px);
+    }
+}
+// seg_head.0 weights for the input-gradient conv: Wd[d][t][o] = W0[o][8 - t][d]  (flipped taps)
+__global__ __launch_bounds__(256) void conv_dgrad_weight_kernel(const float* __restrict__ W0, float* __restrict__ Wd,
+                                                                int D) {
+    const size_t total = (size_t)D * 9 * MID;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int o = (int)(i % MID), t = (int)((i / MID) % 9), d = (int)(i / (MID * 9));
+        Wd[i] = W0[((size_t)o * 9 + (8 - t)) * D + d];
+    }
+}
+
+// ---- embeddings backward: dpos[1+t] = sum_b dX[b*Np+t];  dpos[0] = dcls = sum_b dX[B*Np+b] ----
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dX, float* __restrict__ dpos,
+                                                        float* __restrict__ dcls, int B, int Np, int D) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)(Np + 1) * D) return;
+    const int d = (int)(i % D), n = (int)(i / D);
+    float s = 0.f;
+    if (n == 0) {
+        for (int b = 0; b < B; ++b) s += dX[((size_t)B * Np + b) * D + d];
+        dcls[d] = s;
+    } else {
+        for (int b = 0; b < B; ++b) s += dX[((size_t)b * Np + n - 1) * D + d];
+    }
+    dpos[i] = s;
+}
+
+// ---- Adam (torch.optim.Adam defaults, single fused pass over the flat arena) --------------------
+// exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n4, float b1,
+                                                   float b2, float eps, float step_size, float inv_bc2_sqrt,
+                                                   float grad_scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gv[e] * grad_scale;
+            mv[e] = mv[e] + (gr - mv[e]) * (1.0f - b1);
+            vv[e] = vv[e] * b2 + (1.0f - b2) * gr * gr;
+            const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
+            pv[e] = pv[e] - step_size * (mv[e] / denom);
+        }
+        ((f32x4*)p)[i] = pv;
+        ((f32x4*)m)[i] = mv;
+        ((f32x4*)v)[i] = vv;
+    }
+}
+
+inline int grid_for(size_t n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+
+}  // namespace
+
+size_t colsum_scratch_floats(int M, int N) { return (size_t)((M + 255) / 256) * N; }
+int launch_colsum(const float* X, float* out, float* scratch, int M, int N, int ld, hipStream_t s) {
+    const int chunks = (M + 255) / 256;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, s, X, scratch, M, N, ld);
+    VITSEG_LAUNCH_CHECK("colsum_partial");
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, s, scratch, out, chunks, N);
+    VITSEG_LAUNCH_CHECK("colsum_finish");
+    return VITSEG_OK;
+}
+
+size_t layernorm_bwd_scratch_floats(int rows, int D) { return (size_t)((rows + 63) / 64) * 2 * D; }
+int launch_layernorm_bwd(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out, float* dw,
+                         float* db, float* scratch, int rows, int D, float eps, hipStream_t s) {
+    VITSEG_CHECK_ARG(D % 4 == 0 && D <= 1024, VITSEG_ESHAPE, "layernorm_bwd: D=%d must be a multiple of 4, <= 1024", D);
+    const int blocks = (rows + 63) / 64, nvl = (D / 4 + 63) / 64;
+#define VITSEG_LNB(NV)                                                                                            \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(blocks), dim3(256), 0, s, x, w, g, dres_in, dres_out,     \
+                       scratch, rows, D, eps)
+    if (nvl <= 1) VITSEG_LNB(1);
+    else if (nvl <= 2) VITSEG_LNB(2);
+    else if (nvl <= 3) VITSEG_LNB(3);
+    else VITSEG_LNB(4);
+#undef VITSEG_LNB
+    VITSEG_LAUNCH_CHECK("layernorm_bwd");
+    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, s, scratch, dw, db, blocks, D);
+    VITSEG_LAUNCH_CHECK("layernorm_bwd_finish");
+    return VITSEG_OK;
+}
+
+int launch_upsample_bwd(const float* G, float* dZ, int B, int C, int g, int S, hipStream_t s) {
+    const size_t cells = (size_t)B * C * g * g;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, G, dZ, B, C, g, S);
+    VITSEG_LAUNCH_CHECK("upsample_bwd");
+    return VITSEG_OK;
+}
+
+size_t head1x1_bwd_scratch_floats(int B, int Np, int C) { return (size_t)((B * Np + 63) / 64) * C * MID; }
+int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* dFpre, float* dW2, float* db2,
+                       float* scratch, int B, int Np, int C, hipStream_t s) {
+    VITSEG_CHECK_ARG(C <= 32, VITSEG_ESHAPE, "training supports at most 32 classes (got %d)", C);
+    const int blocks = (B * Np + 63) / 64;
+    hipLaunchKernelGGL(head1x1_bwd_kernel, dim3(blocks), dim3(256), 0, s, dZ, F, W2, dFpre, scratch, B, Np, C);
+    VITSEG_LAUNCH_CHECK("head1x1_bwd");
+    // scratch is [blocks][C*256]: column sums over the blocks
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C * MID + 255) / 256), dim3(256), 0, s, scratch, dW2, blocks, C * MID);
+    VITSEG_LAUNCH_CHECK("head1x1_bwd_finish");
+    hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(C), dim3(256), 0, s, dZ, db2, B, Np, C);
+    VITSEG_LAUNCH_CHECK("head_bias_bwd");
+    return VITSEG_OK;
+}
+
+int launch_im2col3x3(const float* H, float* T, int B, int g, int D, hipStream_t s) {
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for((size_t)B * g * g * 9 * (D / 4))), dim3(256), 0, s, H, T, B, g, D);
+    VITSEG_LAUNCH_CHECK("im2col3x3");
+    return VITSEG_OK;
+}
+int launch_im2col_patch(const float* img, float* T, int B, int Cin, int S, int P, hipStream_t s) {
+    hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for((size_t)B * (S / P) * (S / P) * (Cin * P * P / 4))), dim3(256),
+                       0, s, img, T, B, Cin, S, P);
+    VITSEG_LAUNCH_CHECK("im2col_patch");
+    return VITSEG_OK;
+}
+int launch_conv_dgrad_weight(const float* W0, float* Wd, int D, hipStream_t s) {
+    hipLaunchKernelGGL(conv_dgrad_weight_kernel, dim3(grid_for((size_t)D * 9 * MID)), dim3(256), 0, s, W0, Wd, D);
+    VITSEG_LAUNCH_CHECK("conv_dgrad_weight");
+    return VITSEG_OK;
+}
+int launch_embed_bwd(const float* dX, float* dpos, float* dcls, int B, int Np, int D, hipStream_t s) {
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)(((size_t)(Np + 1) * D + 255) / 256)), dim3(256), 0, s, dX, dpos,
+                       dcls, B, Np, D);
+    VITSEG_LAUNCH_CHECK("embed_bwd");
+    return VITSEG_OK;
+}
+int launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step,
+                float grad_scale, hipStream_t s) {
+    VITSEG_CHECK_ARG(n % 4 == 0 && step >= 1, VITSEG_EINVAL, "adam: n %% 4 != 0 or step < 1");
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, p, g, m, v, n / 4, b1, b2, eps,
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+    VITSEG_LAUNCH_CHECK("adam");
+    return VITSEG_OK;
+}
+
+}  // namespace vitseg

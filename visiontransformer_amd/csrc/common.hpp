@@ -55,6 +55,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // exact (erf) GELU, activations.py:78-83
 __device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
 
+// d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+__device__ __forceinline__ float gelu_erf_grad(float u) {
+    const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+    return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+}
+
 // GELU for tensors that are rounded to bf16 right away (relative precision 2^-9): erf by
 // Abramowitz-Stegun 7.1.28, erf x = 1 - (1 + a1 x + ... + a6 x^6)^-16, |abs error| <= 3e-7 -- three
 // orders below the bf16 rounding of the result -- at ~16 plain VALU ops instead of libm's erff.

@@ -95,7 +95,12 @@ __device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const ARow<T>& r, int
 //   <1,1>/<2,1>: "thin" row tiles (<= 32 / <= 64 valid rows: the CLS rows that follow the B*Np patch
 //   rows); the 4 waves split the 128 columns so such a tile costs 1/4 (1/2) of a regular one and is
 //   scheduled first, instead of adding a whole extra round of blocks to the launch.
-template <typename T, typename OutT, int AMODE, int EPI, int MI, int NI>
+// TA / TB: operand storage form.  0 ("N-form"): [row][k], the reduction index is contiguous (activations,
+// nn.Linear weights).  1 ("T-form", fp32 only): [k][row], the reduction index is the slow one -- what the
+// backward GEMMs meet (dgrad reads W as [n][k] with n the reduction; wgrad reads dY and X with the token
+// index as the reduction).  T-form tiles are staged as [32 k][128 rows] and read one float per lane per
+// MFMA (conflict-free: consecutive lanes = consecutive rows), so no transposed copies are ever made.
+template <typename T, typename OutT, int AMODE, int EPI, int MI, int NI, int TA = 0, int TB = 0>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM * BKF], int m0, int n0, int a_row0,
                                           int b_col0) {
     constexpr int CE = Elem<T>::CE, BKE = Elem<T>::BKE;
@@ -110,9 +115,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+    static_assert(sizeof(T) == 4 || (TA == 0 && TB == 0), "T-form operands are implemented for fp32 only");
     const int li = lane & 31, lh = lane >> 5;
     const int sw = (li >> 1) & 7;
-    const int a_off = (a_row0 + li) * BK, b_off = (b_col0 + li) * BK;
+    const int a_off = TA ? a_row0 + li : (a_row0 + li) * BK, b_off = TB ? b_col0 + li : (b_col0 + li) * BK;
 
     // Fragment registers are double-buffered one MFMA group (16 MFMAs = 1024 matrix-pipe cycles)
     // ahead, so no LDS latency is exposed: group j+1's ds_reads are issued before group j's MFMAs.
@@ -121,10 +127,25 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
     f32x4 a[2][MI], b[2][NI];
     auto lfrag = [&](int buf, int j, int slot) {
         const int ch = (((2 * j + lh) ^ sw) << 2);
+        const int kq = (8 * j + 4 * lh) * BM;  // T-form: element e of the group is k = 8j + 4h + e
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[slot][mi] = *(const f32x4*)&lds[buf][0][a_off + mi * 32 * BK + ch];
+        for (int mi = 0; mi < MI; ++mi) {
+            if constexpr (TA) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[slot][ni] = *(const f32x4*)&lds[buf][1][b_off + ni * 32 * BK + ch];
+                for (int e = 0; e < 4; ++e) a[slot][mi][e] = lds[buf][0][kq + e * BM + a_off + mi * 32];
+            } else {
+                a[slot][mi] = *(const f32x4*)&lds[buf][0][a_off + mi * 32 * BK + ch];
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            if constexpr (TB) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[slot][ni][e] = lds[buf][1][kq + e * BN + b_off + ni * 32];
+            } else {
+                b[slot][ni] = *(const f32x4*)&lds[buf][1][b_off + ni * 32 * BK + ch];
+            }
+        }
     };
     // one group = the MFMAs fed by one 16-byte chunk per operand: 4 k-steps of 32x32x2 (fp32, quarter
     // q = one float of the chunk) or 1 k-step of 32x32x16 (bf16, issued with quarter 0)
@@ -153,37 +174,60 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
 
     const int KT = (p.K + BKE - 1) / BKE;
     if constexpr (sizeof(T) == 4) {
-        // ---- global -> register staging: thread owns chunk lc of rows lr + 32 i ----
+        // ---- global -> register staging ----
+        // N-form: thread owns 16-B chunk lc (of 8) of rows lr + 32 i.  T-form: chunk tc (of 32) of k rows tr + 8 i.
         const int lc = tid & 7, lr = tid >> 3;
+        const int tc = tid & 31, tr = tid >> 5;
         ARow<T> arow[4];
         const T* wrow[4];
         bool wvalid[4];
-    #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            arow[i] = make_arow<T, AMODE>(p, m0 + lr + 32 * i);
-            const int n = n0 + lr + 32 * i;
-            wvalid[i] = n < p.N;
-            wrow[i] = (const T*)p.W + (size_t)(wvalid[i] ? n : 0) * p.K;
+        if constexpr (!TA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) arow[i] = make_arow<T, AMODE>(p, m0 + lr + 32 * i);
         }
+        if constexpr (!TB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + lr + 32 * i;
+                wvalid[i] = n < p.N;
+                wrow[i] = (const T*)p.W + (size_t)(wvalid[i] ? n : 0) * p.ldw;
+            }
+        }
+        const bool ta_col_ok = m0 + tc * 4 < p.M, tb_col_ok = n0 + tc * 4 < p.N;
         f32x4 ra[4], rb[4];
         bool oka[4], okb[4];
         auto gload = [&](int kt) {
             const int k = kt * BKE + lc * CE;
             const int kc = min(k, p.K - CE);
-    #pragma unroll
+#pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ra[i] = load_a<T, AMODE>(p, arow[i], k, oka[i]);
-                rb[i] = *(const f32x4*)(wrow[i] + kc);
-                okb[i] = wvalid[i] && k < p.K;
+                if constexpr (TA) {
+                    const int kr = kt * BKE + tr + 8 * i;
+                    oka[i] = ta_col_ok && kr < p.K;
+                    ra[i] = *(const f32x4*)((const T*)p.A + (size_t)(oka[i] ? kr : 0) * p.lda +
+                                            (oka[i] ? m0 + tc * 4 : 0));
+                } else {
+                    ra[i] = load_a<T, AMODE>(p, arow[i], k, oka[i]);
+                }
+                if constexpr (TB) {
+                    const int kr = kt * BKE + tr + 8 * i;
+                    okb[i] = tb_col_ok && kr < p.K;
+                    rb[i] = *(const f32x4*)((const T*)p.W + (size_t)(okb[i] ? kr : 0) * p.ldw +
+                                            (okb[i] ? n0 + tc * 4 : 0));
+                } else {
+                    rb[i] = *(const f32x4*)(wrow[i] + kc);
+                    okb[i] = wvalid[i] && k < p.K;
+                }
             }
         };
-        const int wpos = lr * BK + ((lc ^ ((lr >> 1) & 7)) << 2);  // + 32*i rows -> same swizzle term
+        const int wpos = lr * BK + ((lc ^ ((lr >> 1) & 7)) << 2);  // N-form; + 32*i rows -> same swizzle term
+        const int tpos = tr * BM + tc * 4;                          // T-form: [k][128], + 8*i k-rows
         auto swrite = [&](int buf) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    #pragma unroll
+#pragma unroll
             for (int i = 0; i < 4; ++i) {
-                *(f32x4*)&lds[buf][0][wpos + 32 * i * BK] = oka[i] ? ra[i] : z;
-                *(f32x4*)&lds[buf][1][wpos + 32 * i * BK] = okb[i] ? rb[i] : z;
+                *(f32x4*)&lds[buf][0][TA ? tpos + 8 * i * BM : wpos + 32 * i * BK] = oka[i] ? ra[i] : z;
+                *(f32x4*)&lds[buf][1][TB ? tpos + 8 * i * BN : wpos + 32 * i * BK] = okb[i] ? rb[i] : z;
             }
         };
         gload(0);
@@ -232,7 +276,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
             const int row = (wave * 4 + i) * 8 + (lane >> 3);
             const int cpos = (lane & 7) ^ ((row >> 1) & 7);
             const int m = min(m0 + row, p.M - 1), n = min(n0 + row, p.N - 1);
-            wsrc[i] = (const T*)p.W + (size_t)n * p.K + cpos * CE;
+            wsrc[i] = (const T*)p.W + (size_t)n * p.ldw + cpos * CE;
             if (AMODE == A_PLAIN) {
                 asrc[i] = (const T*)p.A + (size_t)m * p.lda + cpos * CE;
                 ay[i] = ax[i] = 0;
@@ -326,8 +370,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                 if (grow >= p.M) continue;
                 f32x4 v = *(const f32x4*)&wl[row * 64 + c4];
                 const size_t o = (size_t)grow * p.ldc + gcol;
-                f32x4 extra = {0.f, 0.f, 0.f, 0.f};
-                if (EPI == EPI_RESADD) extra = *(const f32x4*)(p.R + o);
+                f32x4 extra = {0.f, 0.f, 0.f, 0.f}, aux4 = {0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_RESADD || EPI == EPI_DGELU) extra = *(const f32x4*)(p.R + o);
                 if (EPI == EPI_POS) extra = *(const f32x4*)(p.R + (size_t)(1 + grow % p.Np) * p.N + gcol);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -335,8 +379,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                     if (EPI == EPI_GELU) x = (sizeof(T) == 4) ? gelu_erf(x) : gelu_erf_fast(x);
                     if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
                     if (EPI == EPI_RESADD || EPI == EPI_POS) x = extra[e] + x;
+                    if (EPI == EPI_DGELU) x *= gelu_erf_grad(extra[e]);
+                    if (EPI == EPI_GELU && p.aux) aux4[e] = v[e] + bias4[e];
                     v[e] = x;
                 }
+                if (EPI == EPI_GELU && p.aux) *(f32x4*)((float*)p.aux + o) = aux4;  // pre-activation, for backward
                 if constexpr (sizeof(OutT) == 4) {
                     *(f32x4*)(C + o) = v;
                 } else {
@@ -350,7 +397,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
     }
 }
 
-template <typename T, typename OutT, int AMODE, int EPI>
+template <typename T, typename OutT, int AMODE, int EPI, int TA = 0, int TB = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][BM * BKF];  // [buffer][A|W][row*32 + swizzled chunk]
 
@@ -382,17 +429,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int rows_valid = p.M - m0;
     if (rows_valid <= 32)
-        gemm_tile<T, OutT, AMODE, EPI, 1, 1>(p, lds, m0, n0, 0, wave * 32);
+        gemm_tile<T, OutT, AMODE, EPI, 1, 1, TA, TB>(p, lds, m0, n0, 0, wave * 32);
     else if (rows_valid <= 64)
-        gemm_tile<T, OutT, AMODE, EPI, 2, 1>(p, lds, m0, n0, 0, wave * 32);
+        gemm_tile<T, OutT, AMODE, EPI, 2, 1, TA, TB>(p, lds, m0, n0, 0, wave * 32);
     else
-        gemm_tile<T, OutT, AMODE, EPI, 2, 2>(p, lds, m0, n0, (wave >> 1) * 64, (wave & 1) * 64);
+        gemm_tile<T, OutT, AMODE, EPI, 2, 2, TA, TB>(p, lds, m0, n0, (wave >> 1) * 64, (wave & 1) * 64);
 }
 
-template <typename T, typename OutT, int AMODE, int EPI>
-int launch_one(const GemmArgs& a, hipStream_t s) {
+template <typename T, typename OutT, int AMODE, int EPI, int TA = 0, int TB = 0>
+int launch_one(GemmArgs a, hipStream_t s) {
+    if (a.ldw == 0) a.ldw = TB ? a.N : a.K;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_kernel<T, OutT, AMODE, EPI>), dim3(tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel<T, OutT, AMODE, EPI, TA, TB>), dim3(tiles), dim3(256), 0, s, a);
     VITSEG_LAUNCH_CHECK("gemm");
     return VITSEG_OK;
 }
@@ -420,6 +468,24 @@ int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s) {
         return launch_one<float, float, A_CONV3, EPI_RELU>(a, s);
     }
     set_error("gemm_f32: unsupported amode/epilogue %d/%d", amode, epi);
+    return VITSEG_EINVAL;
+}
+
+// Backward GEMMs in fp32 (no transposed copies, see gemm_tile):
+//   dgrad  dX[M,K]  = dY[M,N] . W[N,K]        -> A N-form, B T-form;  epi: plain or * gelu'(R)
+//   wgrad  dW[N,K]  = dY[M,N]^T . X[M,K]      -> A T-form, B T-form;  plain
+// In GemmArgs terms M/N are always the OUTPUT rows/cols and K the reduction length.
+int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, hipStream_t s) {
+    VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, VITSEG_EINVAL, "gemm_bwd: bad M/N/K %d %d %d", a.M, a.N, a.K);
+    VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0, VITSEG_ESHAPE,
+                     "gemm_bwd: leading dimensions must be multiples of 4");
+    VITSEG_CHECK_ARG(ta || a.K % 4 == 0, VITSEG_ESHAPE, "gemm_bwd: K %% 4");
+    VITSEG_CHECK_ARG(!ta || a.M % 4 == 0, VITSEG_ESHAPE, "gemm_bwd: M %% 4 for a T-form A");
+    if (amode == A_PLAIN && !ta && tb && epi == EPI_BIAS) return launch_one<float, float, A_PLAIN, EPI_BIAS, 0, 1>(a, s);
+    if (amode == A_PLAIN && !ta && tb && epi == EPI_DGELU) return launch_one<float, float, A_PLAIN, EPI_DGELU, 0, 1>(a, s);
+    if (amode == A_PLAIN && ta && tb && epi == EPI_BIAS) return launch_one<float, float, A_PLAIN, EPI_BIAS, 1, 1>(a, s);
+    if (amode == A_CONV3 && !ta && !tb && epi == EPI_BIAS) return launch_one<float, float, A_CONV3, EPI_BIAS, 0, 0>(a, s);
+    set_error("gemm_bwd: unsupported combination amode %d ta %d tb %d epi %d", amode, ta, tb, epi);
     return VITSEG_EINVAL;
 }
 

@@ -17,7 +17,8 @@ enum Epi {
     EPI_GELU = 1,    // C = gelu_erf(acc + bias)                      (a7 fc1)
     EPI_RESADD = 2,  // C = R + acc + bias   (R may alias C)          (a8 residual adds)
     EPI_RELU = 3,    // C = max(acc + bias, 0)                        (a11 conv3x3)
-    EPI_POS = 4      // C = acc + bias + pos[1 + m % Np]              (a3 position embeddings)
+    EPI_POS = 4,     // C = acc + bias + pos[1 + m % Np]              (a3 position embeddings)
+    EPI_DGELU = 5    // C = acc * gelu'(R)                            (backward through the MLP activation)
 };
 
 struct GemmArgs {
@@ -28,12 +29,15 @@ struct GemmArgs {
     void* C;
     int M, N, K;
     int lda, ldc;
+    int ldw;            // leading dimension of W (0 = dense: K for N-form, N for T-form)
+    void* aux;          // EPI_GELU: optional second output, the pre-activation (saved for backward)
     // geometry for A_PATCH / A_CONV3 / EPI_POS
     int S, P, g, Np, Cin, D;
     const void* zeros;  // >= 128 zero bytes (bf16 A_CONV3: source of the padding taps)
 };
 
 int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s);
+int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, hipStream_t s);
 int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s);
 
 // LayerNorm over the last dim (a4); out_bf16 selects the bf16-output variant.
@@ -41,7 +45,11 @@ int launch_layernorm(const float* x, const float* w, const float* b, void* y, in
                      bool out_bf16, hipStream_t s);
 
 // Multi-head self-attention core (a6) on the patches-first row layout.
-int launch_attention_f32(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s);
+// lse (optional): fp32 [B, A, Np+1] log2-domain log-sum-exp per query (CLS last), saved for the backward
+int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, hipStream_t s);
+// dqkv[Mt,3D] from dctx[Mt,D]; dvec: scratch fp32 [B, A, Np+1]
+int launch_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dvec,
+                             float* dqkv, int B, int Np, int A, hipStream_t s);
 int launch_attention_bf16(const void* qkv, void* ctx, int B, int Np, int A, hipStream_t s);
 
 // seg_head.2 (1x1 conv) on the ReLU'd mid features -> NCHW low-res logits (a11)
@@ -58,5 +66,22 @@ int launch_ce_loss(const float* Z, const void* target, int target_is_u8, float* 
 int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int Np, int D, hipStream_t s);
 
 int launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+
+// ---- backward pass (backward.hip) ----
+size_t colsum_scratch_floats(int M, int N);
+int launch_colsum(const float* X, float* out, float* scratch, int M, int N, int ld, hipStream_t s);
+size_t layernorm_bwd_scratch_floats(int rows, int D);
+int launch_layernorm_bwd(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out, float* dw,
+                         float* db, float* scratch, int rows, int D, float eps, hipStream_t s);
+int launch_upsample_bwd(const float* G, float* dZ, int B, int C, int g, int S, hipStream_t s);
+size_t head1x1_bwd_scratch_floats(int B, int Np, int C);
+int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* dFpre, float* dW2, float* db2,
+                       float* scratch, int B, int Np, int C, hipStream_t s);
+int launch_im2col3x3(const float* H, float* T, int B, int g, int D, hipStream_t s);
+int launch_im2col_patch(const float* img, float* T, int B, int Cin, int S, int P, hipStream_t s);
+int launch_conv_dgrad_weight(const float* W0, float* Wd, int D, hipStream_t s);
+int launch_embed_bwd(const float* dX, float* dpos, float* dcls, int B, int Np, int D, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step,
+                float grad_scale, hipStream_t s);
 
 }  // namespace vitseg

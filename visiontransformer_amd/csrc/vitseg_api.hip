@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "plan.hpp"
 
 namespace vitseg {
 
@@ -26,110 +27,7 @@ int hip_fail(hipError_t e, const char* what) {
 
 namespace {
 
-constexpr int MID = 256;
-constexpr size_t ALIGN_F = 64;  // arena tensors start on 256-byte boundaries
-
-inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-struct Shape {
-    int C, P, D, L, A, S, I, Cin, g, Np, N, Kp;
-};
-
-int check_config(const vitseg_config* c, Shape* s) {
-    VITSEG_CHECK_ARG(c != nullptr, VITSEG_EINVAL, "config is null");
-    VITSEG_CHECK_ARG(c->num_classes >= 1 && c->num_classes <= 255, VITSEG_ESHAPE, "num_classes %d out of [1,255]",
-                     c->num_classes);
-    VITSEG_CHECK_ARG(c->patch_size >= 4 && c->patch_size % 4 == 0, VITSEG_ESHAPE,
-                     "patch_size %d must be a positive multiple of 4", c->patch_size);
-    VITSEG_CHECK_ARG(c->image_size > 0 && c->image_size % c->patch_size == 0, VITSEG_ESHAPE,
-                     "image_size %d is not a multiple of patch_size %d", c->image_size, c->patch_size);
-    VITSEG_CHECK_ARG(c->num_heads > 0 && c->hidden_size == 64 * c->num_heads, VITSEG_ESHAPE,
-                     "hidden_size %d / num_heads %d: this build needs head_dim 64", c->hidden_size, c->num_heads);
-    VITSEG_CHECK_ARG(c->hidden_size <= 2048, VITSEG_ESHAPE, "hidden_size %d > 2048", c->hidden_size);
-    VITSEG_CHECK_ARG(c->intermediate_size > 0 && c->intermediate_size % 4 == 0, VITSEG_ESHAPE,
-                     "intermediate_size %d must be a multiple of 4", c->intermediate_size);
-    VITSEG_CHECK_ARG(c->num_layers >= 1, VITSEG_ESHAPE, "num_layers %d", c->num_layers);
-    VITSEG_CHECK_ARG(c->num_channels == 3, VITSEG_ESHAPE, "num_channels %d (reference: 3)", c->num_channels);
-    s->C = c->num_classes;
-    s->P = c->patch_size;
-    s->D = c->hidden_size;
-    s->L = c->num_layers;
-    s->A = c->num_heads;
-    s->S = c->image_size;
-    s->I = c->intermediate_size;
-    s->Cin = c->num_channels;
-    s->g = s->S / s->P;
-    s->Np = s->g * s->g;
-    s->N = s->Np + 1;
-    s->Kp = s->Cin * s->P * s->P;
-    return VITSEG_OK;
-}
-
-size_t tensor_numel(const Shape& s, int t) {
-    const size_t D = s.D, I = s.I;
-    switch (t) {
-        case VITSEG_T_CLS: return D;
-        case VITSEG_T_POS: return (size_t)s.N * D;
-        case VITSEG_T_PATCH_W: return D * s.Kp;
-        case VITSEG_T_PATCH_B: return D;
-        case VITSEG_T_LN1_W: case VITSEG_T_LN1_B: case VITSEG_T_LN2_W: case VITSEG_T_LN2_B: return D;
-        case VITSEG_T_WQKV: return 3 * D * D;
-        case VITSEG_T_BQKV: return 3 * D;
-        case VITSEG_T_WO: return D * D;
-        case VITSEG_T_BO: return D;
-        case VITSEG_T_W1: return I * D;
-        case VITSEG_T_B1: return I;
-        case VITSEG_T_W2: return D * I;
-        case VITSEG_T_B2: return D;
-        case VITSEG_T_LNF_W: case VITSEG_T_LNF_B: return D;
-        case VITSEG_T_HEAD0_W: return (size_t)MID * 9 * D;
-        case VITSEG_T_HEAD0_B: return MID;
-        case VITSEG_T_HEAD2_W: return (size_t)s.C * MID;
-        case VITSEG_T_HEAD2_B: return s.C;
-    }
-    return 0;
-}
-
-inline bool per_layer(int t) { return t >= VITSEG_T_LN1_W && t <= VITSEG_T_B2; }
-
-// Arena order = forward order: embeddings, layer 0 .. L-1, final norm, head.
-struct Layout {
-    size_t pre[4];                   // CLS, POS, PATCH_W, PATCH_B
-    size_t layer0;                   // offset of layer 0
-    size_t layer_stride;             // floats per layer
-    size_t in_layer[VITSEG_T_B2 + 1];  // offset inside a layer, indexed by tensor id
-    size_t post[VITSEG_T_COUNT];     // LNF.., indexed by tensor id
-    size_t total;
-};
-
-Layout make_layout(const Shape& s) {
-    Layout l{};
-    size_t off = 0;
-    for (int t = VITSEG_T_CLS; t <= VITSEG_T_PATCH_B; ++t) {
-        l.pre[t] = off;
-        off += up(tensor_numel(s, t), ALIGN_F);
-    }
-    l.layer0 = off;
-    size_t lo = 0;
-    for (int t = VITSEG_T_LN1_W; t <= VITSEG_T_B2; ++t) {
-        l.in_layer[t] = lo;
-        lo += up(tensor_numel(s, t), ALIGN_F);
-    }
-    l.layer_stride = lo;
-    off += lo * s.L;
-    for (int t = VITSEG_T_LNF_W; t < VITSEG_T_COUNT; ++t) {
-        l.post[t] = off;
-        off += up(tensor_numel(s, t), ALIGN_F);
-    }
-    l.total = off;
-    return l;
-}
-
-inline size_t tensor_offset(const Layout& l, int t, int layer) {
-    if (t <= VITSEG_T_PATCH_B) return l.pre[t];
-    if (per_layer(t)) return l.layer0 + (size_t)layer * l.layer_stride + l.in_layer[t];
-    return l.post[t];
-}
+using namespace plan;
 
 // ---- workspace plan -------------------------------------------------------------
 struct Plan {
@@ -333,7 +231,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         {
             ProfScope ps(VITSEG_K_ATTENTION, 4.0 * batch * s.A * (double)s.N * s.N * 64, st);
             rc = lp ? launch_attention_bf16(QKV, H, batch, s.Np, s.A, st)
-                    : launch_attention_f32((const float*)QKV, (float*)H, batch, s.Np, s.A, st);
+                    : launch_attention_f32((const float*)QKV, (float*)H, nullptr, batch, s.Np, s.A, st);
             if (rc) return rc;
         }
         g = GemmArgs{};
@@ -442,12 +340,36 @@ int vitseg_op_linear_bf16(const void* A, const void* Wt, const float* bias, cons
     return launch_gemm_bf16(g, A_PLAIN, epilogue, (hipStream_t)stream);
 }
 
+int vitseg_op_gemm_f32(const float* A, const float* Wt, const float* R, float* C, int M, int N, int K, int ta, int tb,
+                       int epilogue, void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "gemm: null pointer");
+    GemmArgs g{};
+    g.A = A; g.W = Wt; g.R = R; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = ta ? M : K; g.ldw = tb ? N : K; g.ldc = N;
+    if (!ta && !tb) return launch_gemm_f32(g, A_PLAIN, epilogue, (hipStream_t)stream);
+    return launch_gemm_f32_bwd(g, A_PLAIN, ta, tb, epilogue, (hipStream_t)stream);
+}
+
+// forward (saving the log-sum-exp) followed by the backward of the attention core; scratch: B*A*(Np+1) floats
+int vitseg_op_attention_bwd_f32(const float* qkv, const float* dctx, float* ctx_out, float* lse_out, float* scratch,
+                                float* dqkv, int batch, int num_patches, int num_heads, void* stream) {
+    VITSEG_CHECK_ARG(qkv && dctx && ctx_out && lse_out && scratch && dqkv, VITSEG_EINVAL, "attention_bwd: null pointer");
+    if (int rc = launch_attention_f32(qkv, ctx_out, lse_out, batch, num_patches, num_heads, (hipStream_t)stream)) return rc;
+    return launch_attention_bwd_f32(qkv, ctx_out, dctx, lse_out, scratch, dqkv, batch, num_patches, num_heads,
+                                    (hipStream_t)stream);
+}
+
+int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out,
+                                float* dw, float* db, float* scratch, int rows, int D, float eps, void* stream) {
+    return launch_layernorm_bwd(x, w, g, dres_in, dres_out, dw, db, scratch, rows, D, eps, (hipStream_t)stream);
+}
+
 int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream) {
     return launch_attention_bf16(qkv, ctx, batch, num_patches, num_heads, (hipStream_t)stream);
 }
 
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
-    return launch_attention_f32(qkv, ctx, batch, num_patches, num_heads, (hipStream_t)stream);
+    return launch_attention_f32(qkv, ctx, nullptr, batch, num_patches, num_heads, (hipStream_t)stream);
 }
 
 int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask, int batch, int C, int g, int S,

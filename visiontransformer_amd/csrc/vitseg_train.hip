@@ -1,0 +1,299 @@
+// Training entry points of libvitseg (fp32): forward with saved activations, backward, fused Adam.
+// Replaces what autograd + torch.optim.Adam run behind LightningViTModel.training_step /
+// configure_optimizers (/root/reference/model/CE/classes.py:276-285, :296-297).  Dropout is not
+// applied (p = 0): train-mode bitwise parity with torch's RNG stream is impossible anyway
+//  and the parity tests run with dropout off.
+#include "kernels.hpp"
+#include "plan.hpp"
+
+using namespace vitseg;
+using namespace vitseg::plan;
+
+namespace {
+
+// ---- training workspace: per-layer saved activations + backward temporaries (all fp32) ----
+struct LayerBufs {
+    size_t xin, h1, qkv, ctx, lse, xmid, h2, upre, uact;
+};
+struct TrainPlan {
+    size_t Mt, Mp;
+    size_t layer0, layer_stride;  // per-layer block
+    LayerBufs lb;                 // offsets inside a layer block
+    size_t xfinal, hf, f, z;      // after the last layer
+    size_t dxa, dxb, dh, dqkv, du, dctx, dvec, g, dz, df, t, wd, scratch, ce_partial, total;
+};
+
+TrainPlan make_train_plan(const Shape& s, int B) {
+    TrainPlan p{};
+    p.Mp = (size_t)B * s.Np;
+    p.Mt = p.Mp + B;
+    const size_t MtD = p.Mt * s.D * 4, MtI = p.Mt * (size_t)s.I * 4;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += up(bytes, 256);
+        return o;
+    };
+    // one layer block
+    p.lb.xin = take(MtD);
+    p.lb.h1 = take(MtD);
+    p.lb.qkv = take(3 * MtD);
+    p.lb.ctx = take(MtD);
+    p.lb.lse = take((size_t)B * s.A * s.N * 4);
+    p.lb.xmid = take(MtD);
+    p.lb.h2 = take(MtD);
+    p.lb.upre = take(MtI);
+    p.lb.uact = take(MtI);
+    p.layer_stride = off;
+    p.layer0 = 0;
+    off = p.layer_stride * s.L;
+    p.xfinal = take(MtD);
+    p.hf = take(p.Mp * s.D * 4);
+    p.f = take(p.Mp * MID * 4);
+    p.z = take((size_t)B * s.C * s.Np * 4);
+    p.dxa = take(MtD);
+    p.dxb = take(MtD);
+    p.dh = take(MtD);
+    p.dqkv = take(3 * MtD);
+    p.du = take(MtI);
+    p.dctx = take(MtD);
+    p.dvec = take((size_t)B * s.A * s.N * 4);
+    p.g = take((size_t)B * s.C * s.S * s.S * 4);
+    p.dz = take((size_t)B * s.C * s.Np * 4);
+    p.df = take(p.Mp * MID * 4);
+    const size_t tcols = (size_t)(9 * s.D > s.Kp ? 9 * s.D : s.Kp);
+    p.t = take(p.Mp * tcols * 4);
+    p.wd = take((size_t)s.D * 9 * MID * 4);
+    size_t sc = colsum_scratch_floats((int)p.Mt, s.I > 3 * s.D ? s.I : 3 * s.D);
+    const size_t sc2 = layernorm_bwd_scratch_floats((int)p.Mt, s.D), sc3 = head1x1_bwd_scratch_floats(B, s.Np, s.C);
+    sc = sc > sc2 ? sc : sc2;
+    sc = sc > sc3 ? sc : sc3;
+    p.scratch = take(sc * 4);
+    p.ce_partial = take(ce_partial_count(B, s.S) * 8);
+    p.total = off;
+    return p;
+}
+
+struct Ctx {
+    Shape s;
+    TrainPlan p;
+    Layout lay;
+    const float* params;
+    char* ws;
+    hipStream_t st;
+    int B;
+    float eps;
+    const float* W(int t, int l = 0) const { return params + tensor_offset(lay, t, l); }
+    float* L(int l, size_t off) const { return (float*)(ws + p.layer0 + (size_t)l * p.layer_stride + off); }
+    float* T(size_t off) const { return (float*)(ws + off); }
+};
+
+int init_ctx(Ctx& c, const vitseg_config* cfg, const float* params, int B, int precision, void* ws, size_t ws_bytes,
+             void* stream) {
+    if (int rc = check_config(cfg, &c.s)) return rc;
+    VITSEG_CHECK_ARG(precision == VITSEG_F32, VITSEG_EINVAL, "training is implemented for VITSEG_F32 only (got %d)",
+                     precision);
+    VITSEG_CHECK_ARG(params && ws && B >= 1, VITSEG_EINVAL, "null pointer or batch < 1");
+    VITSEG_CHECK_ARG(c.s.C <= 32, VITSEG_ESHAPE, "training supports at most 32 classes (got %d)", c.s.C);
+    c.p = make_train_plan(c.s, B);
+    VITSEG_CHECK_ARG(ws_bytes >= c.p.total, VITSEG_EWORKSPACE, "training workspace %zu < required %zu", ws_bytes,
+                     c.p.total);
+    c.lay = make_layout(c.s);
+    c.params = params;
+    c.ws = (char*)ws;
+    c.st = (hipStream_t)stream;
+    c.B = B;
+    c.eps = cfg->layer_norm_eps;
+    return VITSEG_OK;
+}
+
+GemmArgs lin(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda,
+             int ldc) {
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.R = R; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vitseg_train_workspace(const vitseg_config* cfg, int batch, int precision, size_t* bytes) {
+    Shape s;
+    if (int rc = check_config(cfg, &s)) return rc;
+    VITSEG_CHECK_ARG(batch >= 1 && bytes, VITSEG_EINVAL, "batch %d / null out pointer", batch);
+    VITSEG_CHECK_ARG(precision == VITSEG_F32, VITSEG_EINVAL, "training is implemented for VITSEG_F32 only");
+    *bytes = make_train_plan(s, batch).total;
+    return VITSEG_OK;
+}
+
+int vitseg_forward_train(const vitseg_config* cfg, const float* params, const float* x, int batch, int precision,
+                         float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    Ctx c;
+    if (int rc = init_ctx(c, cfg, params, batch, precision, workspace, workspace_bytes, stream)) return rc;
+    VITSEG_CHECK_ARG(x, VITSEG_EINVAL, "x is null");
+    const Shape& s = c.s;
+    const int Mt = (int)c.p.Mt, Mp = (int)c.p.Mp, D = s.D, I = s.I;
+    hipStream_t st = c.st;
+    int rc;
+    // embeddings -> Xin[0]
+    {
+        float* X0 = c.L(0, c.p.lb.xin);
+        GemmArgs g = lin(x, c.W(VITSEG_T_PATCH_W), c.W(VITSEG_T_PATCH_B), c.W(VITSEG_T_POS), X0, Mp, D, s.Kp, 0, D);
+        g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
+        if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st))) return rc;
+        if ((rc = launch_cls_rows(c.W(VITSEG_T_CLS), c.W(VITSEG_T_POS), X0, batch, s.Np, D, st))) return rc;
+    }
+    for (int l = 0; l < s.L; ++l) {
+        float* Xin = c.L(l, c.p.lb.xin);
+        float* H1 = c.L(l, c.p.lb.h1);
+        float* QKV = c.L(l, c.p.lb.qkv);
+        float* CTX = c.L(l, c.p.lb.ctx);
+        float* Xmid = c.L(l, c.p.lb.xmid);
+        float* H2 = c.L(l, c.p.lb.h2);
+        float* Xout = l + 1 < s.L ? c.L(l + 1, c.p.lb.xin) : c.T(c.p.xfinal);
+        if ((rc = launch_layernorm(Xin, c.W(VITSEG_T_LN1_W, l), c.W(VITSEG_T_LN1_B, l), H1, Mt, D, c.eps, false, st)))
+            return rc;
+        GemmArgs g = lin(H1, c.W(VITSEG_T_WQKV, l), c.W(VITSEG_T_BQKV, l), nullptr, QKV, Mt, 3 * D, D, D, 3 * D);
+        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_BIAS, st))) return rc;
+        if ((rc = launch_attention_f32(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, st))) return rc;
+        g = lin(CTX, c.W(VITSEG_T_WO, l), c.W(VITSEG_T_BO, l), Xin, Xmid, Mt, D, D, D, D);
+        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_RESADD, st))) return rc;
+        if ((rc = launch_layernorm(Xmid, c.W(VITSEG_T_LN2_W, l), c.W(VITSEG_T_LN2_B, l), H2, Mt, D, c.eps, false, st)))
+            return rc;
+        g = lin(H2, c.W(VITSEG_T_W1, l), c.W(VITSEG_T_B1, l), nullptr, c.L(l, c.p.lb.uact), Mt, I, D, D, I);
+        g.aux = c.L(l, c.p.lb.upre);
+        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_GELU, st))) return rc;
+        g = lin(c.L(l, c.p.lb.uact), c.W(VITSEG_T_W2, l), c.W(VITSEG_T_B2, l), Xmid, Xout, Mt, D, I, I, D);
+        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_RESADD, st))) return rc;
+    }
+    float* Hf = c.T(c.p.hf);
+    float* F = c.T(c.p.f);
+    float* Z = c.T(c.p.z);
+    if ((rc = launch_layernorm(c.T(c.p.xfinal), c.W(VITSEG_T_LNF_W), c.W(VITSEG_T_LNF_B), Hf, Mp, D, c.eps, false, st)))
+        return rc;
+    {
+        GemmArgs g = lin(Hf, c.W(VITSEG_T_HEAD0_W), c.W(VITSEG_T_HEAD0_B), nullptr, F, Mp, MID, 9 * D, 0, MID);
+        g.g = s.g; g.Np = s.Np; g.D = D;
+        if ((rc = launch_gemm_f32(g, A_CONV3, EPI_RELU, st))) return rc;
+        if ((rc = launch_head1x1(F, c.W(VITSEG_T_HEAD2_W), c.W(VITSEG_T_HEAD2_B), Z, batch, s.Np, s.C, st))) return rc;
+    }
+    if (logits) return launch_upsample(Z, logits, nullptr, batch, s.C, s.g, s.S, st);
+    return VITSEG_OK;
+}
+
+int vitseg_backward(const vitseg_config* cfg, const float* params, const float* x, int batch, int precision,
+                    const void* target, int target_is_u8, const float* grad_logits, float* grads, float* loss,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    Ctx c;
+    if (int rc = init_ctx(c, cfg, params, batch, precision, workspace, workspace_bytes, stream)) return rc;
+    VITSEG_CHECK_ARG(x && grads, VITSEG_EINVAL, "x / grads is null");
+    VITSEG_CHECK_ARG((target != nullptr) != (grad_logits != nullptr), VITSEG_EINVAL,
+                     "pass exactly one of target (fused CE) and grad_logits");
+    VITSEG_CHECK_ARG(!target || loss, VITSEG_EINVAL, "fused CE needs the loss output pointer");
+    const Shape& s = c.s;
+    const int Mt = (int)c.p.Mt, Mp = (int)c.p.Mp, D = s.D, I = s.I, B = batch;
+    hipStream_t st = c.st;
+    int rc;
+    auto G = [&](int t, int l = 0) { return grads + tensor_offset(c.lay, t, l); };
+    float* scratch = c.T(c.p.scratch);
+    {
+        hipError_t e = hipMemsetAsync(grads, 0, c.lay.total * sizeof(float), st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(grads)");
+    }
+    // dgrad: dX[M,Kd] = dY[M,Nd] . W[Nd,Kd]   (A N-form, W T-form)
+    auto dgrad = [&](const float* dY, const float* Wt, float* dX, int M, int Nd, int Kd, int epi, const float* R) {
+        GemmArgs g = lin(dY, Wt, nullptr, R, dX, M, Kd, Nd, Nd, Kd);
+        g.ldw = Kd;
+        return launch_gemm_f32_bwd(g, A_PLAIN, 0, 1, epi, st);
+    };
+    // wgrad: dW[Nd,Kd] = dY[M,Nd]^T . X[M,Kd]   (both T-form, reduction over the M token rows)
+    auto wgrad = [&](const float* dY, const float* X, float* dW, int M, int Nd, int Kd) {
+        GemmArgs g = lin(dY, X, nullptr, nullptr, dW, Nd, Kd, M, Nd, Kd);
+        g.ldw = Kd;
+        return launch_gemm_f32_bwd(g, A_PLAIN, 1, 1, EPI_BIAS, st);
+    };
+
+    // ---- 1. loss -> d logits -> d low-res logits ----
+    float* dZ = c.T(c.p.dz);
+    const float* Gfull = grad_logits;
+    if (target) {
+        if ((rc = launch_ce_loss(c.T(c.p.z), target, target_is_u8, c.T(c.p.g), (double*)(c.ws + c.p.ce_partial), loss, B,
+                                 s.C, s.g, s.S, st)))
+            return rc;
+        Gfull = c.T(c.p.g);
+    }
+    if ((rc = launch_upsample_bwd(Gfull, dZ, B, s.C, s.g, s.S, st))) return rc;
+
+    // ---- 2. seg_head backward ----
+    float* dF = c.T(c.p.df);
+    float* Hf = c.T(c.p.hf);
+    float* dH = c.T(c.p.dh);
+    if ((rc = launch_head1x1_bwd(dZ, c.T(c.p.f), c.W(VITSEG_T_HEAD2_W), dF, G(VITSEG_T_HEAD2_W), G(VITSEG_T_HEAD2_B),
+                                 scratch, B, s.Np, s.C, st)))
+        return rc;
+    if ((rc = launch_colsum(dF, G(VITSEG_T_HEAD0_B), scratch, Mp, MID, MID, st))) return rc;
+    if ((rc = launch_im2col3x3(Hf, c.T(c.p.t), B, s.g, D, st))) return rc;
+    if ((rc = wgrad(dF, c.T(c.p.t), G(VITSEG_T_HEAD0_W), Mp, MID, 9 * D))) return rc;
+    if ((rc = launch_conv_dgrad_weight(c.W(VITSEG_T_HEAD0_W), c.T(c.p.wd), D, st))) return rc;
+    {
+        GemmArgs g = lin(dF, c.T(c.p.wd), nullptr, nullptr, dH, Mp, D, 9 * MID, 0, D);
+        g.g = s.g; g.Np = s.Np; g.D = MID;
+        if ((rc = launch_gemm_f32_bwd(g, A_CONV3, 0, 0, EPI_BIAS, st))) return rc;
+    }
+    // ---- 3. final LayerNorm backward (patch rows; the dropped CLS rows get zero gradient) ----
+    float* dXa = c.T(c.p.dxa);
+    float* dXb = c.T(c.p.dxb);
+    {
+        hipError_t e = hipMemsetAsync(dXa + (size_t)Mp * D, 0, (size_t)(Mt - Mp) * D * sizeof(float), st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dX cls rows)");
+    }
+    if ((rc = launch_layernorm_bwd(c.T(c.p.xfinal), c.W(VITSEG_T_LNF_W), dH, nullptr, dXa, G(VITSEG_T_LNF_W),
+                                   G(VITSEG_T_LNF_B), scratch, Mp, D, c.eps, st)))
+        return rc;
+
+    // ---- 4. encoder layers, last to first ----
+    float* dU = c.T(c.p.du);
+    float* dQKV = c.T(c.p.dqkv);
+    float* dCTX = c.T(c.p.dctx);
+    for (int l = s.L - 1; l >= 0; --l) {
+        // MLP: Xout = Xmid + fc2(gelu(fc1(H2)))
+        if ((rc = launch_colsum(dXa, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
+        if ((rc = wgrad(dXa, c.L(l, c.p.lb.uact), G(VITSEG_T_W2, l), Mt, D, I))) return rc;
+        if ((rc = dgrad(dXa, c.W(VITSEG_T_W2, l), dU, Mt, D, I, EPI_DGELU, c.L(l, c.p.lb.upre)))) return rc;
+        if ((rc = launch_colsum(dU, G(VITSEG_T_B1, l), scratch, Mt, I, I, st))) return rc;
+        if ((rc = wgrad(dU, c.L(l, c.p.lb.h2), G(VITSEG_T_W1, l), Mt, I, D))) return rc;
+        if ((rc = dgrad(dU, c.W(VITSEG_T_W1, l), dH, Mt, I, D, EPI_BIAS, nullptr))) return rc;
+        if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xmid), c.W(VITSEG_T_LN2_W, l), dH, dXa, dXb, G(VITSEG_T_LN2_W, l),
+                                       G(VITSEG_T_LN2_B, l), scratch, Mt, D, c.eps, st)))
+            return rc;
+        // attention: Xmid = Xin + o_proj(attn(qkv(H1)))
+        if ((rc = launch_colsum(dXb, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
+        if ((rc = wgrad(dXb, c.L(l, c.p.lb.ctx), G(VITSEG_T_WO, l), Mt, D, D))) return rc;
+        if ((rc = dgrad(dXb, c.W(VITSEG_T_WO, l), dCTX, Mt, D, D, EPI_BIAS, nullptr))) return rc;
+        if ((rc = launch_attention_bwd_f32(c.L(l, c.p.lb.qkv), c.L(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
+                                           c.T(c.p.dvec), dQKV, B, s.Np, s.A, st)))
+            return rc;
+        if ((rc = launch_colsum(dQKV, G(VITSEG_T_BQKV, l), scratch, Mt, 3 * D, 3 * D, st))) return rc;
+        if ((rc = wgrad(dQKV, c.L(l, c.p.lb.h1), G(VITSEG_T_WQKV, l), Mt, 3 * D, D))) return rc;
+        if ((rc = dgrad(dQKV, c.W(VITSEG_T_WQKV, l), dH, Mt, 3 * D, D, EPI_BIAS, nullptr))) return rc;
+        if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xin), c.W(VITSEG_T_LN1_W, l), dH, dXb, dXa, G(VITSEG_T_LN1_W, l),
+                                       G(VITSEG_T_LN1_B, l), scratch, Mt, D, c.eps, st)))
+            return rc;
+    }
+    // ---- 5. embeddings ----
+    if ((rc = launch_embed_bwd(dXa, G(VITSEG_T_POS), G(VITSEG_T_CLS), B, s.Np, D, st))) return rc;
+    if ((rc = launch_colsum(dXa, G(VITSEG_T_PATCH_B), scratch, Mp, D, D, st))) return rc;
+    if ((rc = launch_im2col_patch(x, c.T(c.p.t), B, s.Cin, s.S, s.P, st))) return rc;
+    return wgrad(dXa, c.T(c.p.t), G(VITSEG_T_PATCH_W), Mp, D, s.Kp);
+}
+
+int vitseg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n_floats, float lr,
+                     float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+    VITSEG_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, VITSEG_EINVAL, "adam: null pointer");
+    return launch_adam(params, grads, exp_avg, exp_avg_sq, n_floats, lr, beta1, beta2, eps, step, grad_scale,
+                       (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -49,7 +49,8 @@ class LightningViTModel(nn.Module):
         return loss
 
     def configure_optimizers(self):
-        return torch.optim.Adam(self.parameters(), lr=1e-5)  # classes.py:296-297
+        from .optim import FusedAdam
+        return FusedAdam(self.parameters(), lr=1e-5)  # Adam(lr=1e-5), classes.py:296-297
 
     # checkpoint schema: every key prefixed with "model." like the reference module tree
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):

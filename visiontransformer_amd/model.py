@@ -25,6 +25,35 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+class _LogitsFn(torch.autograd.Function):
+    """logits = forward(x) with libvitseg's backward: d loss / d logits -> d loss / d arena."""
+
+    @staticmethod
+    def forward(ctx, arena, model, x):
+        ctx.model, ctx.x = model, x
+        return model._forward_train(x, want_logits=True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        grads, _ = ctx.model._backward(ctx.x, grad_logits=dlogits.to(torch.float32).contiguous())
+        return grads, None, None
+
+
+class _CELossFn(torch.autograd.Function):
+    """Fused CE: forward + loss + backward in one go (no [B,C,S,S] logits tensor is returned)."""
+
+    @staticmethod
+    def forward(ctx, arena, model, x, target):
+        model._forward_train(x, want_logits=False)
+        grads, loss = model._backward(x, target=target)
+        ctx.grads = grads
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        return ctx.grads * dloss, None, None, None
+
+
 class ViTSegmentationModel(nn.Module):
     def __init__(self, num_classes, patch_size, hidden_size, num_hidden_layers, num_attention_heads, *,
                  image_size: int = 224, intermediate_size: int = 3072, precision: str = "fp32",
@@ -162,13 +191,54 @@ class ViTSegmentationModel(nn.Module):
         _lib.check(rc)
         return logits, mask
 
+    # ------------------------------------------------------------------ training plumbing
+    def _train_workspace(self, batch: int) -> torch.Tensor:
+        key = ("train", batch)
+        ws = self._ws.get(key)
+        if ws is None:
+            if self.precision != _lib.F32:
+                raise NotImplementedError("training through libvitseg is built for precision='fp32' only")
+            ws = torch.empty(_lib.train_workspace(self.cfg, batch, _lib.F32), dtype=torch.uint8,
+                             device=self.arena.device)
+            self._ws = {key: ws}
+        return ws
+
+    def _forward_train(self, x: torch.Tensor, want_logits: bool):
+        self._check_input(x)
+        x = x.to(torch.float32).contiguous()
+        B, S = x.shape[0], self.cfg.image_size
+        ws = self._train_workspace(B)
+        logits = torch.empty((B, self.cfg.num_classes, S, S), dtype=torch.float32, device=x.device) \
+            if want_logits else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().vitseg_forward_train(
+                C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(), x.data_ptr(), B, _lib.F32,
+                _ptr(logits), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        return logits
+
+    def _backward(self, x: torch.Tensor, target: Optional[torch.Tensor] = None,
+                  grad_logits: Optional[torch.Tensor] = None):
+        x = x.to(torch.float32).contiguous()
+        B = x.shape[0]
+        ws = self._train_workspace(B)
+        grads = torch.empty_like(self.arena.data)
+        loss = torch.zeros((), dtype=torch.float32, device=x.device) if target is not None else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().vitseg_backward(
+                C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(), x.data_ptr(), B, _lib.F32,
+                _ptr(target), int(target is not None and target.dtype == torch.uint8), _ptr(grad_logits),
+                grads.data_ptr(), _ptr(loss), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        return grads, loss
+
+    def _needs_grad(self) -> bool:
+        return torch.is_grad_enabled() and self.arena.requires_grad
+
     # ------------------------------------------------------------------ reference surface
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """logits [B, C, H, W] (model/CE/classes.py:246-262), eval-mode arithmetic."""
-        if torch.is_grad_enabled() and self.arena.requires_grad and self.training:
-            raise NotImplementedError(
-                "training forward/backward through libvitseg is not built yet (round 1 ships inference); "
-                "call model.eval() / torch.no_grad() for inference")
+        """logits [B, C, H, W] (model/CE/classes.py:246-262).  Differentiable w.r.t. the parameters when
+        autograd is on (dropout p = 0; the backward runs in libvitseg, see vitseg_backward)."""
+        if self._needs_grad():
+            return _LogitsFn.apply(self.arena, self, x)
         logits, _ = self._run(x, True, False)
         return logits
 
@@ -183,11 +253,11 @@ class ViTSegmentationModel(nn.Module):
         """`nn.CrossEntropyLoss()(self(x), target)` (model/CE/classes.py:268,280) as a device scalar, without
         materialising the [B, C, S, S] logits: forward to the low-res map, then the fused upsample+CE kernel.
         `target`: class indices [B, S, S], torch.long (reference) or torch.uint8, on the model's device."""
-        if torch.is_grad_enabled() and self.arena.requires_grad and self.training:
-            raise NotImplementedError("the backward pass through libvitseg is not built yet; use torch.no_grad()")
         S, B = self.cfg.image_size, x.shape[0]
         if tuple(target.shape) != (B, S, S) or target.dtype not in (torch.int64, torch.uint8):
             raise ValueError(f"target must be int64/uint8 [B, {S}, {S}], got {target.dtype} {tuple(target.shape)}")
+        if self._needs_grad():
+            return _CELossFn.apply(self.arena, self, x, target.to(self.arena.device).contiguous())
         with torch.no_grad():
             _, _ = self._run(x, False, True)  # fills the low-res logits (mask output is a by-product)
             low = self.debug_buffer(B, _lib.BUF_LOWRES)

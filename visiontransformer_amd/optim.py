@@ -1,0 +1,40 @@
+"""Fused Adam over the flat parameter arena (one kernel launch per step).
+
+Same update as `torch.optim.Adam(params, lr)` with default betas/eps, weight_decay 0, amsgrad off --
+what `LightningViTModel.configure_optimizers` builds in the reference (model/CE/classes.py:296-297).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.numel() % 4 == 0):
+                    raise RuntimeError("FusedAdam needs contiguous fp32 HIP tensors whose size is a multiple of 4")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                g = p.grad.contiguous()
+                with torch.cuda.device(p.device):
+                    _lib.check(_lib.lib().vitseg_adam_step(
+                        p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                        group["lr"], group["betas"][0], group["betas"][1], group["eps"], st["step"], grad_scale,
+                        torch.cuda.current_stream().cuda_stream))
+                p._version  # noqa: B018  (in-place update through the raw pointer; bump the version below)
+                p.add_(0)   # marks the arena as modified so the bf16 shadow / cached views refresh
+        return loss
