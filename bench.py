@@ -83,6 +83,58 @@ def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.
     return base, parity
 
 
+def bench_train(args, cfg, model, x, rank, world, dev, barrier):
+    """One step = LightningViTModel.training_step + backward + (N>1: RCCL all-reduce of the flat gradient
+    arena) + Adam(lr=1e-5): BASELINE configs[2]/[3] in fp32 (the bf16 training kernels are not built yet)."""
+    from visiontransformer_amd.dist import allreduce_grads
+    from visiontransformer_amd.optim import FusedAdam
+    B = args.batch
+    y = torch.from_numpy(synth.make_targets(cfg, B, seed=0, first_image=rank * B, size=cfg.image_size)).to(dev)
+    model.train()
+    opt = FusedAdam(model.parameters(), lr=1e-5)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model.ce_loss(x, y)
+        loss.backward()
+        allreduce_grads(model.arena.grad)
+        opt.step(grad_scale=1.0 / world)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        flops_img = 3.0 * cfg.forward_flops_per_image()
+        peak = PEAK_TFLOPS["f32"]
+        print(json.dumps({
+            "metric": "images/sec (512×512) ViT-B/16 seg, 1/2/4/8 MI355X + mask argmax match",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ViT-B/16 seg TRAINING step (forward + CE + backward + Adam), batch {B}/GPU x "
+                                   f"512x512, fp32, dropout 0", "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"data-parallel x{world}, flat-arena gradient all-reduce (RCCL)"},
+            "whole_model": {"flops_per_image": flops_img,
+                            "achieved_tflops_per_gpu": round(value / world * flops_img / 1e12, 2),
+                            "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},
+            "final_loss": float(loss.detach())}), flush=True)
+    barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +143,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="train: one step = forward + CE + backward + gradient all-reduce + Adam (fp32)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,6 +174,9 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+
+    if args.mode == "train":
+        return bench_train(args, cfg, model, x, rank, world, dev, barrier)
 
     with torch.no_grad():
         for _ in range(args.warmup):

@@ -55,3 +55,35 @@ def test_predict_sharded_gloo_world2():
             p.join(timeout=120)
             assert p.exitcode == 0
         assert ok
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from visiontransformer_amd.dist import allreduce_grads
+    n = 1_000_003  # not a multiple of the bucket size
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    allreduce_grads(g, bucket_mb=1.0)  # 4 buckets, issued tail-first
+    expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    if rank == 0:
+        q.put(bool(torch.equal(g, expect)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_grads_gloo_world2():
+    """The training exchange step: bucketed sum of the flat gradient arena (backend nccl = RCCL on the GPUs)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok

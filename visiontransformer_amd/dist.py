@@ -59,3 +59,25 @@ def predict_sharded(images: torch.Tensor, predict_fn: Callable[[torch.Tensor], t
         l, h = shard_range(B, r, world)
         out.append(parts[r][: h - l])
     return torch.cat(out)
+
+
+def allreduce_grads(flat_grad: torch.Tensor, bucket_mb: float = 64.0) -> None:
+    """Sum `flat_grad` (the gradient of the flat parameter arena) over all ranks, in place.
+
+    The arena is laid out in forward order, so its TAIL (head, last layers) is what the backward pass
+    finishes first: buckets are issued from the tail towards the front, each as one large asynchronous
+    all-reduce (xGMI rings are per-link bound, so few large messages beat many small ones), then waited
+    for together.  The optimizer applies 1/world (`FusedAdam.step(grad_scale=1/world)`), which makes the
+    update equal to the single-process update on the global batch (mean loss over all pixels)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    n = flat_grad.numel()
+    per = max(1, int(bucket_mb * (1 << 20) / flat_grad.element_size()))
+    works = []
+    hi = n
+    while hi > 0:
+        lo = max(0, hi - per)
+        works.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        hi = lo
+    for w in works:
+        w.wait()
