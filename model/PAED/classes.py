@@ -1,8 +1,8 @@
-"""Entry-point shim: the reference's scripts do `from classes import ...` (model/CE/*.py); these
-names resolve to the MI355X implementation.  Dataset / smp classes of the reference's classes.py are
-host-side I/O and are out of scope."""
+"""Entry-point shim for the reference's model/PAED scripts (`from classes import ...`, e.g.
+model/PAED/ViTscript.py:8,66): the names resolve to the MI355X implementation."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from visiontransformer_amd import LightningViTModel, ViTSegmentationModel  # noqa: E402,F401
+from visiontransformer_amd import ViTSegmentationModel  # noqa: E402,F401
+from visiontransformer_amd.paed import LightningViTModel, PAEDTrainer, paed_loss_multiclass_soft  # noqa: E402,F401

@@ -190,3 +190,38 @@ def test_fused_adam_matches_torch_adam():
         ob.step()
         assert (a.detach() - b.detach()).abs().max().item() < 2e-9, step
     assert (a.detach().cpu() - p0).abs().max().item() > 1e-5  # it did move
+
+
+def test_paed_trainer_step_gradients_match_oracle():
+    """PAEDTrainer (binary BCE + Dice + |soft-PAED|, model/PAED/classes.py:664-701): the loss tail runs as tensor
+    ops on the logits, its gradient reaches the arena through vitseg_backward(grad_logits)."""
+    from visiontransformer_amd import paed
+    from visiontransformer_amd.params import arena_views
+    cfg = ViTSegConfig(1, 16, 192, 2, 3, image_size=96)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=41).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 2, seed=7))
+    g = torch.Generator().manual_seed(3)
+    masks = (torch.rand(2, 128, 128, generator=g) > 0.5).long()
+    sdf_e, sdf_i = torch.rand(2, 64, 64, generator=g) * 4, torch.rand(2, 64, 64, generator=g) * 2
+    # oracle: CPU restatement forward + the same loss tail, autograd in fp64
+    leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    preds = torch.sigmoid(O.forward(x.double(), leaf, cfg))
+    m = O.resize_target(masks, (96, 96)).unsqueeze(1).double()
+    ref = (torch.nn.functional.binary_cross_entropy(preds, m) + 0.1 * paed.dice_loss(preds, m).double()
+           + 5.0 * paed.paed_loss_soft(sdf_e.unsqueeze(1).double(), sdf_i.unsqueeze(1).double(), preds).abs())
+    ref.backward()
+    t = paed.PAEDTrainer(1, 16, 192, 2, 3, image_size=96, device=DEV).train()
+    t.load_state_dict({"model." + k: v for k, v in sd.items()})
+    loss = t.training_step((x.to(DEV), masks.to(DEV), sdf_e.to(DEV), sdf_i.to(DEV)), 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref)) < 1e-5
+    gv = arena_views(cfg, t.model.arena.grad)
+    for k, r in leaf.items():
+        err = (gv[k].cpu().double() - r.grad).abs().max().item()
+        assert err <= 3e-4 * max(r.grad.abs().max().item(), 1e-3), (k, err)
+    # the 17-class module runs too (loss value vs the oracle forward)
+    lm = paed.LightningViTModel(2, 16, 192, 1, 3, image_size=96, device=DEV).train()
+    y17 = torch.randint(0, 17, (2, 128, 128), generator=g)
+    l17 = lm.training_step((x.to(DEV), y17.to(DEV)), 0)
+    l17.backward()
+    assert torch.isfinite(l17) and lm.model.arena.grad.abs().sum() > 0 and lm.model.cfg.num_classes == 17

@@ -1,0 +1,34 @@
+"""CPU: the PAED loss tails (visiontransformer_amd/paed.py) against golden values/gradients produced by the
+REAL reference functions (oracle/make_golden_paed.py, model/PAED/classes.py:336-369, :608-661, :679-681)."""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle.make_golden_paed import paed_inputs
+from visiontransformer_amd import paed
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "paed", "paed_losses.npz"))
+
+
+def test_multiclass_soft_paed_matches_reference():
+    logits, y, *_ = paed_inputs()
+    lg = logits.clone().requires_grad_(True)
+    loss = paed.paed_loss_multiclass_soft(F.one_hot(y, 17).permute(0, 3, 1, 2).float(), torch.softmax(lg, dim=1), 17)
+    loss.backward()
+    assert abs(loss.item() - G["multiclass.loss"][0]) < 1e-9
+    assert np.abs(lg.grad.numpy() - G["multiclass.grad"]).max() < 1e-10
+
+
+def test_binary_paed_bce_dice_matches_reference():
+    _, _, blogits, bmask, sdf_ext, sdf_int = paed_inputs()
+    bl = blogits.clone().requires_grad_(True)
+    preds = torch.sigmoid(bl)
+    p = paed.paed_loss_soft(sdf_ext, sdf_int, preds)
+    d = paed.dice_loss(preds, bmask)
+    total = F.binary_cross_entropy(preds, bmask) + 0.1 * d + 5.0 * p.abs()
+    total.backward()
+    assert abs(p.item() - G["binary.paed"][0]) < 1e-6 and abs(d.item() - G["binary.dice"][0]) < 1e-6
+    assert abs(total.item() - G["binary.total"][0]) < 1e-5
+    assert np.abs(bl.grad.numpy() - G["binary.grad"]).max() < 1e-7

@@ -1,0 +1,157 @@
+"""PAED entry points of the reference (model/PAED/classes.py) on the MI355X model.
+
+`ViTSegmentationModel` is the same class as in model/CE (the reference keeps a byte-identical copy at
+model/PAED/classes.py:372-413); what differs is the loss tail.  The tails are elementwise / small-stencil
+maths on the logits and run as PyTorch-ROCm tensor ops here ("keep as
+PyTorch-ROCm ops initially"); their gradient reaches the parameters through libvitseg's backward
+(`vitseg_backward` with `grad_logits`).  Lightning's logging is replaced by a `logged` dict.
+
+  * `LightningViTModel` -- 17-class soft-PAED loss, Adam(lr=1e-4)          (model/PAED/classes.py:415-487)
+  * `PAEDTrainer`       -- binary BCE + 0.1 Dice + 5 |soft-PAED|, AdamW(1e-4) + ReduceLROnPlateau (:490-701)
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .model import ViTSegmentationModel
+
+
+def paed_loss_multiclass_soft(msk, pred_mask, num_classes=17, sigma=3, class_penalty=True):
+    """Soft PAED for C classes (model/PAED/classes.py:336-369): both the one-hot target and the predicted
+    probabilities are blurred per class with a normalised (6 sigma + 1)^2 Gaussian; the L1 difference of the
+    blurred maps, weighted by 2 * target * (1 - prob) when `class_penalty`, is averaged over space, then
+    classes, then the batch."""
+    C = msk.shape[1]
+    k = int(6 * sigma + 1)
+    ax = torch.arange(k, dtype=torch.float32) - k // 2
+    g1 = torch.exp(-(ax ** 2) / (2 * sigma ** 2))
+    g2 = g1[:, None] * g1[None, :]
+    g2 = (g2 / g2.sum()).to(msk.device)[None, None].repeat(C, 1, 1, 1)
+    blur_t = F.conv2d(msk, g2, padding=k // 2, groups=C)
+    blur_p = F.conv2d(pred_mask, g2, padding=k // 2, groups=C)
+    diff = (blur_t - blur_p).abs()
+    if class_penalty:
+        diff = msk * (1 - pred_mask) * diff * 2
+    return diff.mean(dim=[2, 3]).mean(dim=1).mean()
+
+
+def dice_loss(preds, targets, smooth=1e-6):
+    """1 - (2 |P.T| + s) / (|P| + |T| + s) on the flattened batch (model/PAED/classes.py:608-620)."""
+    p, t = preds.float().reshape(-1), targets.float().reshape(-1)
+    return 1 - (2.0 * (p * t).sum() + smooth) / (p.sum() + t.sum() + smooth)
+
+
+def paed_loss_soft(gt_sdf_ext, gt_sdf_int, preds):
+    """Soft PAED for the binary model (model/PAED/classes.py:623-661): the exterior SDF weights a
+    max-normalised Sobel edge map of the prediction, the interior SDF rewards the prediction itself:
+    1.0 * mean(sdf_ext * edge) - 0.5 * mean(sdf_int * pred).  SDFs [B,1,h,w] are bilinearly resized."""
+    B, _, H, W = preds.shape
+    ext = F.interpolate(gt_sdf_ext, size=(H, W), mode="bilinear", align_corners=False)
+    inn = F.interpolate(gt_sdf_int, size=(H, W), mode="bilinear", align_corners=False)
+    sx = torch.tensor([[1., 0., -1.], [2., 0., -2.], [1., 0., -1.]], device=preds.device, dtype=preds.dtype).view(1, 1, 3, 3)
+    gx = F.conv2d(preds, sx, padding=1)
+    gy = F.conv2d(preds, sx.transpose(2, 3), padding=1)
+    edge = torch.sqrt(gx ** 2 + gy ** 2 + 1e-6)
+    edge = edge / (edge.view(B, -1).max(dim=1)[0].view(B, 1, 1, 1) + 1e-6)
+    return 1 * (ext * edge).mean() - 0.5 * (inn * preds).mean()
+
+
+def iou_score(preds, targets, num_classes=17):
+    """Mean over classes of the batch-mean IoU with 1e-6 smoothing (model/PAED/classes.py:430-447)."""
+    ious = []
+    for c in range(num_classes):
+        p, t = (preds == c).float(), (targets == c).float()
+        inter = (p * t).sum((1, 2))
+        union = (p + t).clamp(0, 1).sum((1, 2))
+        ious.append(((inter + 1e-6) / (union + 1e-6)).mean())
+    return torch.stack(ious).mean()
+
+
+class _Base(nn.Module):
+    def __init__(self, num_classes, patch_size, hidden_size, num_hidden_layers, num_attention_heads, **kw):
+        super().__init__()
+        self.model = ViTSegmentationModel(num_classes, patch_size, hidden_size, num_hidden_layers,
+                                          num_attention_heads, **kw)
+        self.logged = {}
+
+    def forward(self, x):
+        return self.model(x)
+
+    def _resize_target(self, y, size=None):
+        size = size or (self.model.cfg.image_size,) * 2
+        if y.dim() == 4:
+            if y.shape[1] != 1:
+                raise ValueError(f"Expected single-channel mask but got shape {y.shape}")  # :502-503
+            y = y[:, 0]
+        return F.interpolate(y.unsqueeze(1).float(), size=size, mode="nearest").squeeze(1).long()
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        return self.model.state_dict(destination=destination, prefix=prefix + "model.", keep_vars=keep_vars)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        return self.model.load_state_dict(state_dict, strict=strict)
+
+
+class LightningViTModel(_Base):
+    """model/PAED/classes.py:415-487 (the class count is forced to 17 there, :418)."""
+
+    def __init__(self, num_classes, patch_size, hidden_size, num_hidden_layers, num_attention_heads, **kw):
+        super().__init__(17, patch_size, hidden_size, num_hidden_layers, num_attention_heads, **kw)
+        self.num_classes = 17
+
+    def _step(self, batch, tag):
+        x, y = batch
+        y = self._resize_target(y)
+        probs = torch.softmax(self.forward(x), dim=1)
+        onehot = F.one_hot(y, self.num_classes).permute(0, 3, 1, 2).float()
+        loss = paed_loss_multiclass_soft(onehot, probs, num_classes=self.num_classes)
+        self.logged[f"{tag}_loss"] = float(loss.detach())
+        self.logged[f"{tag}_iou"] = float(iou_score(probs.argmax(dim=1), y, self.num_classes))
+        return loss
+
+    def training_step(self, batch, batch_idx):
+        return self._step(batch, "train")
+
+    def validation_step(self, batch, batch_idx):
+        with torch.no_grad():
+            return self._step(batch, "valid")
+
+    def configure_optimizers(self):
+        from .optim import FusedAdam
+        return FusedAdam(self.parameters(), lr=1e-4)  # :486-487
+
+
+class PAEDTrainer(_Base):
+    """model/PAED/classes.py:490-701; scripts build it with num_classes=1 (model/PAED/ViTscript.py:66)."""
+
+    def _forward_step_paed(self, batch, batch_idx, tag="train"):
+        images, masks, sdf_ext, sdf_int = batch
+        masks = self._resize_target(masks).unsqueeze(1).float()
+        preds = torch.sigmoid(self.forward(images))
+        paed = paed_loss_soft(sdf_ext.unsqueeze(1), sdf_int.unsqueeze(1), preds)
+        loss = F.binary_cross_entropy(preds, masks) + 0.1 * dice_loss(preds, masks) + 5.0 * paed.abs()  # :679-681
+        with torch.no_grad():
+            b, m = (preds > 0.5).float(), masks
+            tp, fp, fn = (b * m).sum(), (b * (1 - m)).sum(), ((1 - b) * m).sum()
+            acc = (b == m).float().mean()
+            iou = tp / (tp + fp + fn).clamp_min(1e-12)
+            dice = 2 * tp / (2 * tp + fp + fn).clamp_min(1e-12)
+            prec, rec = tp / (tp + fp).clamp_min(1e-12), tp / (tp + fn).clamp_min(1e-12)
+        for k, v in dict(loss=loss, acc=acc, IoU=iou, dice=dice, precision=prec, recall=rec).items():
+            self.logged[f"{tag}_{k}"] = float(v.detach())
+        return loss, acc, iou, dice, prec, rec
+
+    def training_step(self, batch, batch_idx):
+        return self._forward_step_paed(batch, batch_idx, "train")[0]
+
+    def validation_step(self, batch, batch_idx):
+        with torch.no_grad():
+            return self._forward_step_paed(batch, batch_idx, "val")[0]
+
+    def configure_optimizers(self):
+        opt = torch.optim.AdamW(self.model.parameters(), lr=1e-4)  # :536-548
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=30)
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "monitor": "val_IoU", "interval": "epoch",
+                                                   "frequency": 1}}
