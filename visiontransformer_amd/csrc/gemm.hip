@@ -172,7 +172,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
         }
     };
 
-    const int KT = (p.K + BKE - 1) / BKE;
+    // split-K: blockIdx.y owns K steps [kt0, kt0 + KT) and writes its own partial C (p.C + y * split_stride)
+    const int KT_all = (p.K + BKE - 1) / BKE;
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const int kt0 = (int)((long long)KT_all * split / nsplit);
+    const int KT = (int)((long long)KT_all * (split + 1) / nsplit) - kt0;
     if constexpr (sizeof(T) == 4) {
         // ---- global -> register staging ----
         // N-form: thread owns 16-B chunk lc (of 8) of rows lr + 32 i.  T-form: chunk tc (of 32) of k rows tr + 8 i.
@@ -197,12 +201,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
         f32x4 ra[4], rb[4];
         bool oka[4], okb[4];
         auto gload = [&](int kt) {
-            const int k = kt * BKE + lc * CE;
+            const int k = (kt + kt0) * BKE + lc * CE;
             const int kc = min(k, p.K - CE);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if constexpr (TA) {
-                    const int kr = kt * BKE + tr + 8 * i;
+                    const int kr = (kt + kt0) * BKE + tr + 8 * i;
                     oka[i] = ta_col_ok && kr < p.K;
                     ra[i] = *(const f32x4*)((const T*)p.A + (size_t)(oka[i] ? kr : 0) * p.lda +
                                             (oka[i] ? m0 + tc * 4 : 0));
@@ -210,7 +214,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                     ra[i] = load_a<T, AMODE>(p, arow[i], k, oka[i]);
                 }
                 if constexpr (TB) {
-                    const int kr = kt * BKE + tr + 8 * i;
+                    const int kr = (kt + kt0) * BKE + tr + 8 * i;
                     okb[i] = tb_col_ok && kr < p.K;
                     rb[i] = *(const f32x4*)((const T*)p.W + (size_t)(okb[i] ? kr : 0) * p.ldw +
                                             (okb[i] ? n0 + tc * 4 : 0));
@@ -288,7 +292,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
             }
         }
         auto issue = [&](int kt, int buf) {
-            const int k0 = kt * BKE;
+            const int k0 = (kt + kt0) * BKE;
             int tap = 0, d0 = k0, ky = 1, kx = 1;
             if (AMODE == A_CONV3) {
                 tap = k0 / p.D;  // a 64-wide K step lies inside one tap (D % 64 == 0)
@@ -362,7 +366,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
         if (gcol < p.N) {
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bias4 = *(const f32x4*)(p.bias + gcol);
-            OutT* C = (OutT*)p.C;
+            OutT* C = (OutT*)p.C + (size_t)blockIdx.y * p.split_stride;
 #pragma unroll
             for (int ps = 0; ps < MI * 32 / RPP; ++ps) {
                 const int row = ps * RPP + rr;
@@ -440,7 +444,8 @@ template <typename T, typename OutT, int AMODE, int EPI, int TA = 0, int TB = 0>
 int launch_one(GemmArgs a, hipStream_t s) {
     if (a.ldw == 0) a.ldw = TB ? a.N : a.K;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_kernel<T, OutT, AMODE, EPI, TA, TB>), dim3(tiles), dim3(256), 0, s, a);
+    const int splits = a.splitk > 1 ? a.splitk : 1;
+    hipLaunchKernelGGL((gemm_kernel<T, OutT, AMODE, EPI, TA, TB>), dim3(tiles, splits), dim3(256), 0, s, a);
     VITSEG_LAUNCH_CHECK("gemm");
     return VITSEG_OK;
 }
@@ -475,6 +480,48 @@ int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s) {
 //   dgrad  dX[M,K]  = dY[M,N] . W[N,K]        -> A N-form, B T-form;  epi: plain or * gelu'(R)
 //   wgrad  dW[N,K]  = dY[M,N]^T . X[M,K]      -> A T-form, B T-form;  plain
 // In GemmArgs terms M/N are always the OUTPUT rows/cols and K the reduction length.
+// Split-K for the weight gradients: the output is only a weight matrix (36-144 tiles) while the reduction
+// runs over every token row, so the K range is cut into `splits` slabs (one grid.y slice each, plain
+// stores into partial[split][M][N]) that splitk_reduce_kernel sums in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            size_t n4, int splits) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 acc = ((const f32x4*)partial)[i];
+        for (int sIdx = 1; sIdx < splits; ++sIdx) {
+            const f32x4 v = ((const f32x4*)partial)[(size_t)sIdx * n4 + i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        }
+        ((f32x4*)out)[i] = acc;
+    }
+}
+
+int wgrad_splits(int M, int N, int K) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int splits = (1024 + tiles - 1) / tiles;         // aim at ~2 rounds of 512 resident blocks
+    const int ksteps = (K + 31) / 32;
+    if (splits > ksteps / 4) splits = ksteps / 4;    // keep >= 4 K steps per slab
+    return splits < 1 ? 1 : splits;
+}
+size_t wgrad_scratch_floats(int M, int N, int K) { return (size_t)wgrad_splits(M, N, K) * M * N; }
+
+// dW[M,N] = A^T . W (both T-form) with split-K through `scratch` (>= wgrad_scratch_floats floats; ldc == N)
+int launch_wgrad_f32(GemmArgs a, float* scratch, hipStream_t s) {
+    const int splits = wgrad_splits(a.M, a.N, a.K);
+    if (splits <= 1) return launch_gemm_f32_bwd(a, A_PLAIN, 1, 1, EPI_BIAS, s);
+    VITSEG_CHECK_ARG(a.ldc == a.N && scratch, VITSEG_EINVAL, "wgrad: split-K needs a dense output and scratch");
+    float* out = (float*)a.C;
+    a.C = scratch;
+    a.splitk = splits;
+    a.split_stride = (size_t)a.M * a.N;
+    if (int rc = launch_gemm_f32_bwd(a, A_PLAIN, 1, 1, EPI_BIAS, s)) return rc;
+    const size_t n4 = (size_t)a.M * a.N / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, scratch, out, n4, splits);
+    VITSEG_LAUNCH_CHECK("splitk_reduce");
+    return VITSEG_OK;
+}
+
 int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, hipStream_t s) {
     VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, VITSEG_EINVAL, "gemm_bwd: bad M/N/K %d %d %d", a.M, a.N, a.K);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0, VITSEG_ESHAPE,

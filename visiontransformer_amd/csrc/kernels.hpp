@@ -34,10 +34,14 @@ struct GemmArgs {
     // geometry for A_PATCH / A_CONV3 / EPI_POS
     int S, P, g, Np, Cin, D;
     const void* zeros;  // >= 128 zero bytes (bf16 A_CONV3: source of the padding taps)
+    int splitk;           // > 1: grid.y slices of the K range, each writing C + y * split_stride
+    size_t split_stride;
 };
 
 int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s);
 int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, hipStream_t s);
+size_t wgrad_scratch_floats(int M, int N, int K);
+int launch_wgrad_f32(GemmArgs a, float* scratch, hipStream_t s);
 int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s);
 
 // LayerNorm over the last dim (a4); out_bf16 selects the bf16-output variant.

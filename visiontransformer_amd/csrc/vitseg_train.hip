@@ -20,7 +20,7 @@ struct TrainPlan {
     size_t layer0, layer_stride;  // per-layer block
     LayerBufs lb;                 // offsets inside a layer block
     size_t xfinal, hf, f, z;      // after the last layer
-    size_t dxa, dxb, dh, dqkv, du, dctx, dvec, g, dz, df, t, wd, scratch, ce_partial, total;
+    size_t dxa, dxb, dh, dqkv, du, dctx, dvec, g, dz, df, t, wd, scratch, wscratch, ce_partial, total;
 };
 
 TrainPlan make_train_plan(const Shape& s, int B) {
@@ -69,6 +69,17 @@ TrainPlan make_train_plan(const Shape& s, int B) {
     sc = sc > sc2 ? sc : sc2;
     sc = sc > sc3 ? sc : sc3;
     p.scratch = take(sc * 4);
+    {   // split-K partials of the weight-gradient GEMMs (largest over the shapes the backward uses)
+        const int Mt = (int)p.Mt, Mp = (int)p.Mp;
+        size_t w = wgrad_scratch_floats(s.D, s.I, Mt);
+        auto mx = [&](size_t v) { w = v > w ? v : w; };
+        mx(wgrad_scratch_floats(s.I, s.D, Mt));
+        mx(wgrad_scratch_floats(s.D, s.D, Mt));
+        mx(wgrad_scratch_floats(3 * s.D, s.D, Mt));
+        mx(wgrad_scratch_floats(MID, 9 * s.D, Mp));
+        mx(wgrad_scratch_floats(s.D, s.Kp, Mp));
+        p.wscratch = take(w * 4);
+    }
     p.ce_partial = take(ce_partial_count(B, s.S) * 8);
     p.total = off;
     return p;
@@ -212,7 +223,7 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const float* 
     auto wgrad = [&](const float* dY, const float* X, float* dW, int M, int Nd, int Kd) {
         GemmArgs g = lin(dY, X, nullptr, nullptr, dW, Nd, Kd, M, Nd, Kd);
         g.ldw = Kd;
-        return launch_gemm_f32_bwd(g, A_PLAIN, 1, 1, EPI_BIAS, st);
+        return launch_wgrad_f32(g, c.T(c.p.wscratch), st);
     };
 
     // ---- 1. loss -> d logits -> d low-res logits ----
