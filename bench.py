@@ -228,6 +228,25 @@ def main():
                             "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
         }
+        if args.precision == "f32" and not args.no_cpu_baseline:
+            # informational: the same step on the bf16-operand path (outside the timed region, rank 0 only)
+            m16 = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+                                       cfg.num_attention_heads, image_size=cfg.image_size, precision="bf16",
+                                       device=dev).eval()
+            m16.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+            with torch.no_grad():
+                for _ in range(3):
+                    mk16, lg16 = m16.predict_mask(x, return_logits=True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    mk16, lg16 = m16.predict_mask(x, return_logits=True)
+                torch.cuda.synchronize()
+                dt16 = (time.perf_counter() - t1) / 10
+            out["bf16_path"] = {"images_per_s_per_gpu": round(B / dt16, 1), "ms_per_step": round(dt16 * 1e3, 3),
+                                "logits_max_abs_diff_vs_f32": float((lg16 - logits).abs().max()),
+                                "mask_agreement_vs_f32": float((mk16 == mask).float().mean())}
+            del m16
         if not args.no_cpu_baseline:
             base, parity = cpu_baseline(cfg, sd_np, images_np, logits, mask)
             out["cpu_baseline"] = base

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------- dK, dV
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __restrict__ qkv,
                                                               const float* __restrict__ dctx,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta, float* __restrict__ dqkv,
