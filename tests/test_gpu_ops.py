@@ -131,7 +131,8 @@ def _bf16_round(t):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(128, 128, 64, 0), (257, 192, 128, 0), (788, 576, 192, 1), (1025, 768, 3072, 2),
-                                       (2050, 2304, 768, 0), (33, 96, 64, 2), (130, 3072, 768, 1)])
+                                       (2050, 2304, 768, 0), (33, 96, 64, 2), (130, 3072, 768, 1),
+                                       (4129, 768, 768, 0), (4608, 384, 192, 1), (5000, 200, 3072, 2), (8224, 2304, 768, 0)])
 def test_linear_bf16(M, N, K, epi):
     A, W = _bf16_round(_rand(M, K, seed=M)), _bf16_round(_rand(N, K, seed=N + 1, scale=0.05))
     bias, R = _rand(N, seed=7, scale=0.1), _rand(M, N, seed=11)

@@ -19,6 +19,8 @@
 // from a row-major tile whose chunk index is XOR-swizzled with (row >> 1) & 7 (conflict-free).
 // Global->LDS goes through registers (the gathering loaders need per-chunk zero-fill),
 // double-buffered in LDS with one barrier per K step; fragments are double-buffered in registers.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace vitseg {
@@ -367,33 +369,42 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bias4 = *(const f32x4*)(p.bias + gcol);
             OutT* C = (OutT*)p.C + (size_t)blockIdx.y * p.split_stride;
+            // all LDS reads (and residual / position loads) first, the stores last: in a kernel that contains
+            // LDS-DMA hipcc waits vmcnt(0) before every use of a ds_read result, which would otherwise
+            // serialise the 16 row stores one memory round trip at a time
+            constexpr int NPS = MI * 32 / RPP;
+            f32x4 v[NPS], extra[NPS];
 #pragma unroll
-            for (int ps = 0; ps < MI * 32 / RPP; ++ps) {
+            for (int ps = 0; ps < NPS; ++ps) {
                 const int row = ps * RPP + rr;
-                const int grow = m0 + a_row0 + row;
+                const int grow = min(m0 + a_row0 + row, p.M - 1);
+                v[ps] = *(const f32x4*)&wl[row * 64 + c4];
+                if (EPI == EPI_RESADD || EPI == EPI_DGELU) extra[ps] = *(const f32x4*)(p.R + (size_t)grow * p.ldc + gcol);
+                if (EPI == EPI_POS) extra[ps] = *(const f32x4*)(p.R + (size_t)(1 + grow % p.Np) * p.N + gcol);
+            }
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const int grow = m0 + a_row0 + ps * RPP + rr;
                 if (grow >= p.M) continue;
-                f32x4 v = *(const f32x4*)&wl[row * 64 + c4];
                 const size_t o = (size_t)grow * p.ldc + gcol;
-                f32x4 extra = {0.f, 0.f, 0.f, 0.f}, aux4 = {0.f, 0.f, 0.f, 0.f};
-                if (EPI == EPI_RESADD || EPI == EPI_DGELU) extra = *(const f32x4*)(p.R + o);
-                if (EPI == EPI_POS) extra = *(const f32x4*)(p.R + (size_t)(1 + grow % p.Np) * p.N + gcol);
+                f32x4 aux4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float x = v[e] + bias4[e];
+                    float x = v[ps][e] + bias4[e];
+                    if (EPI == EPI_GELU && p.aux) aux4[e] = x;
                     if (EPI == EPI_GELU) x = (sizeof(T) == 4) ? gelu_erf(x) : gelu_erf_fast(x);
                     if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
-                    if (EPI == EPI_RESADD || EPI == EPI_POS) x = extra[e] + x;
-                    if (EPI == EPI_DGELU) x *= gelu_erf_grad(extra[e]);
-                    if (EPI == EPI_GELU && p.aux) aux4[e] = v[e] + bias4[e];
-                    v[e] = x;
+                    if (EPI == EPI_RESADD || EPI == EPI_POS) x = extra[ps][e] + x;
+                    if (EPI == EPI_DGELU) x *= gelu_erf_grad(extra[ps][e]);
+                    v[ps][e] = x;
                 }
                 if (EPI == EPI_GELU && p.aux) *(f32x4*)((float*)p.aux + o) = aux4;  // pre-activation, for backward
                 if constexpr (sizeof(OutT) == 4) {
-                    *(f32x4*)(C + o) = v;
+                    *(f32x4*)(C + o) = v[ps];
                 } else {
                     uint2 h;
-                    h.x = pack2_bf16(v[0], v[1]);
-                    h.y = pack2_bf16(v[2], v[3]);
+                    h.x = pack2_bf16(v[ps][0], v[ps][1]);
+                    h.y = pack2_bf16(v[ps][2], v[ps][3]);
                     *(uint2*)(C + o) = h;
                 }
             }
@@ -480,6 +491,258 @@ int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s) {
 //   dgrad  dX[M,K]  = dY[M,N] . W[N,K]        -> A N-form, B T-form;  epi: plain or * gelu'(R)
 //   wgrad  dW[N,K]  = dY[M,N]^T . X[M,K]      -> A T-form, B T-form;  plain
 // In GemmArgs terms M/N are always the OUTPUT rows/cols and K the reduction length.
+// =====================================================================================================
+// bf16 GEMM, large-M variant: block 256(M) x 128(N), BK = 64, 8 waves as 4(M) x 2(N) (64x64 per wave,
+// the same per-wave work as the 128x128 kernel), ONE block per CU, 3-stage LDS ring (3 x 48 KiB).
+//
+// Why a second shape: at bf16 rates the 128x128 / 2-blocks-per-CU kernel stages 64 B/clk/CU, i.e. it needs
+// the whole L2 bandwidth of the chip (34 TB/s) at full MFMA rate, and its single-tile prefetch exposes the
+// L2/MALL latency (measured: 30 % MFMA busy, 790 TF/s asymptote, 1260 TF/s with the loads removed).  This
+// tile stages 25 % fewer bytes per FLOP and keeps TWO K steps in flight: the global_load_lds of step kt+2
+// are issued right after the barrier that publishes step kt and are only waited for (counted
+// `s_waitcnt vmcnt(6)`: the 6 DMA pieces of step kt+1 may stay outstanding) two compute phases later.
+// M = B*Np + B: the B*Np patch rows are whole 256-row tiles at 512x512; the CLS rows make one thin tile
+// that is scheduled first and in which only the first wave row computes.
+constexpr int LBM = 256, LBN = 128, LSTAGES = 3;
+
+template <typename OutT, int AMODE, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs p) {
+    typedef bf16_t T;
+    constexpr int CE = 8, BKE = 64, BK = BKF;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [stage][A 256 rows | W 128 rows][32 words]
+    auto stageA = [&](int st) { return lds_raw + st * (LBM + LBN) * BK; };
+    auto stageW = [&](int st) { return lds_raw + st * (LBM + LBN) * BK + LBM * BK; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches below
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + LBN - 1) / LBN, tiles_m = (p.M + LBM - 1) / LBM;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int GN = (size_t)p.K * sizeof(T) <= 2048 ? 8 : 4;
+    const bool thin_last = p.M - (tiles_m - 1) * LBM <= 64 && tiles_m > 1;
+    int tile_m, tile_n;
+    if (thin_last && t < tiles_n) {
+        tile_m = tiles_m - 1;
+        tile_n = t;
+    } else {
+        const int rows = thin_last ? tiles_m - 1 : tiles_m;
+        if (thin_last) t -= tiles_n;
+        const int gsz = rows * GN, ngroups = (tiles_n + GN - 1) / GN;
+        const int grp = min(t / gsz, ngroups - 1);
+        const int rem = t - grp * gsz;
+        const int gcols = min(GN, tiles_n - grp * GN);
+        tile_m = rem / gcols;
+        tile_n = grp * GN + rem - tile_m * gcols;
+    }
+    const int m0 = tile_m * LBM, n0 = tile_n * LBN;
+    const bool computes = (p.M - m0 > 64) || wm == 0;  // thin tile: only the first 64 rows exist
+
+    // ---- DMA assignment: per K step 32 A pieces + 16 W pieces of 1 KiB (8 rows each); wave w issues
+    //      A pieces w*4 .. w*4+3 and W pieces w*2, w*2+1 ----
+    const T* asrc[4];
+    const T* wsrc[2];
+    int ay[4], ax[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int cpos = (lane & 7) ^ ((row >> 1) & 7);
+        const int m = min(m0 + row, p.M - 1);
+        if (AMODE == A_PLAIN) {
+            asrc[i] = (const T*)p.A + (size_t)m * p.lda + cpos * CE;
+            ay[i] = ax[i] = 0;
+        } else {
+            const int bimg = m / p.Np, tt = m - bimg * p.Np;
+            ay[i] = tt / p.g;
+            ax[i] = tt - ay[i] * p.g;
+            asrc[i] = (const T*)p.A + (size_t)m * p.D + cpos * CE;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3);
+        const int cpos = (lane & 7) ^ ((row >> 1) & 7);
+        wsrc[i] = (const T*)p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + cpos * CE;
+    }
+    auto issue = [&](int kt, int st) {
+        const int k0 = kt * BKE;
+        int d0 = k0, ky = 1, kx = 1;
+        if (AMODE == A_CONV3) {
+            const int tap = k0 / p.D;
+            d0 = k0 - tap * p.D;
+            ky = tap / 3;
+            kx = tap - ky * 3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const T* ga;
+            if (AMODE == A_PLAIN) {
+                ga = asrc[i] + k0;
+            } else {
+                const int yy = ay[i] + ky - 1, xx = ax[i] + kx - 1;
+                const bool in = (unsigned)yy < (unsigned)p.g && (unsigned)xx < (unsigned)p.g;
+                ga = in ? asrc[i] + ((ptrdiff_t)(ky - 1) * p.g + (kx - 1)) * p.D + d0 : (const T*)p.zeros + (lane & 7) * CE;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                             (__attribute__((address_space(3))) void*)(stageA(st) + (wave * 4 + i) * 8 * BK),
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(stageW(st) + (wave * 2 + i) * 8 * BK),
+                                             16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    const int sw = (li >> 1) & 7;
+    const int a_off = (wm * 64 + li) * BK, b_off = (wn * 64 + li) * BK;
+    f32x4 a[2][2], b[2][2];
+    auto lfrag = [&](int st, int j, int slot) {
+        const int ch = (((2 * j + lh) ^ sw) << 2);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[slot][mi] = *(const f32x4*)&stageA(st)[a_off + mi * 32 * BK + ch];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b[slot][ni] = *(const f32x4*)&stageW(st)[b_off + ni * 32 * BK + ch];
+    };
+    auto mfma4 = [&](int slot) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[slot][mi]),
+                                                                      __builtin_bit_cast(bf16x8, b[slot][ni]),
+                                                                      acc[mi][ni], 0, 0, 0);
+    };
+
+    const int KT = p.K / BKE;
+    // 3-stage ring: while step kt is computed, steps kt+1 and kt+2 are in flight.  The loop is rotated around
+    // the barrier (group 3 of step kt runs after the barrier that publishes step kt+1, under the first
+    // fragment reads of step kt+1) and sched_barrier pins "next group's ds_reads, then this group's MFMAs".
+    issue(0, 0);
+    if (KT > 1) issue(1, 1);
+    if (KT > 2) issue(2, 2);
+    if (KT > 2)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (KT > 1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int st = 0;
+    if (computes) lfrag(0, 0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int stn = st == 2 ? 0 : st + 1;
+        if (computes) {
+            lfrag(st, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(0);
+            __builtin_amdgcn_sched_barrier(0);
+            lfrag(st, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(1);
+            __builtin_amdgcn_sched_barrier(0);
+            lfrag(st, 3, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kt + 1 < KT) {
+            // step kt+1 has landed once at most the 6 pieces of step kt+2 are outstanding (in-order retire);
+            // lgkmcnt(0): this wave's reads of stage st are complete before anyone refills it
+            if (kt + 2 < KT)
+                asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 3 < KT) issue(kt + 3, st);
+            if (computes) {
+                lfrag(stn, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (computes) mfma4(1);
+        st = stn;
+    }
+
+    // ---- epilogue: per-wave LDS staging, row-vector stores (same scheme as the 128x128 kernel) ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!computes) return;
+    float* wl = lds_raw + wave * 4096;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                wl[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + ni * 32 + li] = acc[mi][ni][r];
+    const int rr = lane >> 4, c4 = (lane & 15) * 4;
+    const int gcol = n0 + wn * 64 + c4;
+    if (gcol >= p.N) return;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *(const f32x4*)(p.bias + gcol);
+    OutT* C = (OutT*)p.C;
+    // all LDS reads (and residual loads) first, stores last: in a kernel that contains LDS-DMA hipcc waits
+    // vmcnt(0) before every use of a ds_read result, which would serialise the stores one by one
+    f32x4 v[16], extra[16];
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+        const int row = ps * 4 + rr;
+        v[ps] = *(const f32x4*)&wl[row * 64 + c4];
+        if (EPI == EPI_RESADD) {
+            const int grow = min(m0 + wm * 64 + row, p.M - 1);
+            extra[ps] = *(const f32x4*)(p.R + (size_t)grow * p.ldc + gcol);
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+        const int grow = m0 + wm * 64 + ps * 4 + rr;
+        const size_t o = (size_t)grow * p.ldc + gcol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[ps][e] + bias4[e];
+            if (EPI == EPI_GELU) x = gelu_erf_fast(x);
+            if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
+            if (EPI == EPI_RESADD) x = extra[ps][e] + x;
+            v[ps][e] = x;
+        }
+        if (grow < p.M) {
+            if constexpr (sizeof(OutT) == 4) {
+                *(f32x4*)(C + o) = v[ps];
+            } else {
+                uint2 h;
+                h.x = pack2_bf16(v[ps][0], v[ps][1]);
+                h.y = pack2_bf16(v[ps][2], v[ps][3]);
+                *(uint2*)(C + o) = h;
+            }
+        }
+    }
+}
+
+template <typename OutT, int AMODE, int EPI>
+int launch_large(GemmArgs a, hipStream_t s) {
+    if (a.ldw == 0) a.ldw = a.K;
+    const int tiles = ((a.M + LBM - 1) / LBM) * ((a.N + LBN - 1) / LBN);
+    const size_t smem = (size_t)LSTAGES * (LBM + LBN) * BKF * sizeof(float);  // 144 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_large_kernel<OutT, AMODE, EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_large)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_large_kernel<OutT, AMODE, EPI>), dim3(tiles), dim3(512), smem, s, a);
+    VITSEG_LAUNCH_CHECK("gemm_bf16_large");
+    return VITSEG_OK;
+}
+
 // Split-K for the weight gradients: the output is only a weight matrix (36-144 tiles) while the reduction
 // runs over every token row, so the K range is cut into `splits` slabs (one grid.y slice each, plain
 // stores into partial[split][M][N]) that splitk_reduce_kernel sums in a fixed order (deterministic).
@@ -543,16 +806,23 @@ int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     VITSEG_CHECK_ARG(a.K % 64 == 0, VITSEG_ESHAPE, "gemm_bf16: K=%d must be a multiple of 64", a.K);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm: N=%d and ldc=%d must be multiples of 4", a.N,
                      a.ldc);
+    // the 256x128 / 3-stage kernel and the 128x128 / 2-stage kernel measure within a few % of each other on the
+    // model's shapes (both ~790 TF/s asymptote); the large one is used where its deeper prefetch helps: long K
+    const char* force = getenv("VITSEG_BF16_TILES");  // "large" / "small" for experiments
+    const bool large = force ? force[0] == 'l' : (a.M >= 4096 && a.K >= 2048);
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 8 == 0, VITSEG_EINVAL, "gemm_bf16: lda %% 8");
         switch (epi) {
-            case EPI_BIAS: return launch_one<bf16_t, bf16_t, A_PLAIN, EPI_BIAS>(a, s);
-            case EPI_GELU: return launch_one<bf16_t, bf16_t, A_PLAIN, EPI_GELU>(a, s);
-            case EPI_RESADD: return launch_one<bf16_t, float, A_PLAIN, EPI_RESADD>(a, s);
+            case EPI_BIAS: return large ? launch_large<bf16_t, A_PLAIN, EPI_BIAS>(a, s)
+                                        : launch_one<bf16_t, bf16_t, A_PLAIN, EPI_BIAS>(a, s);
+            case EPI_GELU: return large ? launch_large<bf16_t, A_PLAIN, EPI_GELU>(a, s)
+                                        : launch_one<bf16_t, bf16_t, A_PLAIN, EPI_GELU>(a, s);
+            case EPI_RESADD: return large ? launch_large<float, A_PLAIN, EPI_RESADD>(a, s)
+                                          : launch_one<bf16_t, float, A_PLAIN, EPI_RESADD>(a, s);
         }
     } else if (amode == A_CONV3 && epi == EPI_RELU) {
         VITSEG_CHECK_ARG(a.D % 64 == 0 && a.zeros, VITSEG_ESHAPE, "hidden size must be a multiple of 64");
-        return launch_one<bf16_t, float, A_CONV3, EPI_RELU>(a, s);
+        return large ? launch_large<float, A_CONV3, EPI_RELU>(a, s) : launch_one<bf16_t, float, A_CONV3, EPI_RELU>(a, s);
     }
     set_error("gemm_bf16: unsupported amode/epilogue %d/%d", amode, epi);
     return VITSEG_EINVAL;
