@@ -85,7 +85,7 @@ def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.
 
 def bench_train(args, cfg, model, x, rank, world, dev, barrier):
     """One step = LightningViTModel.training_step + backward + (N>1: RCCL all-reduce of the flat gradient
-    arena) + Adam(lr=1e-5): BASELINE configs[2]/[3] in fp32 (the bf16 training kernels are not built yet)."""
+    arena) + Adam(lr=1e-5): BASELINE configs[2]/[3] (--precision bf16 = mixed precision, --batch 64)."""
     from visiontransformer_amd.dist import allreduce_grads
     from visiontransformer_amd.optim import FusedAdam
     B = args.batch
@@ -119,14 +119,15 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
     if rank == 0:
         value = world * B * args.steps / elapsed
         flops_img = 3.0 * cfg.forward_flops_per_image()
-        peak = PEAK_TFLOPS["f32"]
+        peak = PEAK_TFLOPS[args.precision]
         print(json.dumps({
             "metric": "images/sec (512×512) ViT-B/16 seg, 1/2/4/8 MI355X + mask argmax match",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"ViT-B/16 seg TRAINING step (forward + CE + backward + Adam), batch {B}/GPU x "
-                                   f"512x512, fp32, dropout 0", "batch_per_gpu": B, "global_batch": B * world,
+                                   f"512x512, {args.precision}, dropout 0", "batch_per_gpu": B,
+                       "global_batch": B * world,
                        "parallelism": f"data-parallel x{world}, flat-arena gradient all-reduce (RCCL)"},
             "whole_model": {"flops_per_image": flops_img,
                             "achieved_tflops_per_gpu": round(value / world * flops_img / 1e12, 2),

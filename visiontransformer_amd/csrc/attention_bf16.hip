@@ -39,7 +39,7 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 
 
 template <bool RAGGED>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                           int B, int Np, int A) {
+                                                           float* __restrict__ lse, int B, int Np, int A) {
     // [buffer][K|V][key * 64 + d] bf16, rows of 128 B with XOR-swizzled 16-B chunks: 32 KiB
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][KB * HD];
 
@@ -206,6 +206,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
     // ---- normalise and store: lane holds d = 32 dt + 8 g4 + 4 lh + e of its query ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    // log-sum-exp of the scaled scores in log2 units, [b][head][token] with the CLS token last (backward)
+    if (lse && q_valid && lh == 0)
+        lse[((size_t)b * A + head) * (Np + 1) + q_local] = m_run * c + __builtin_amdgcn_logf(l_tot);
     if (q_valid) {
         bf16_t* out = ctx + q_row * (size_t)D + head * HD;
 #pragma unroll
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 
 // The B*A CLS queries: one block per (head, image); plain VALU in fp32 on bf16 inputs.
 __global__ __launch_bounds__(256) void attn_cls_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                            int B, int Np, int A) {
+                                                            float* __restrict__ lse, int B, int Np, int A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int N = Np + 1;
     float* sc = sm;
@@ -270,7 +273,9 @@ __global__ __launch_bounds__(256) void attn_cls_bf16_kernel(const bf16_t* __rest
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
-    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    const float ltot = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / ltot;
+    if (lse && tid == 0) lse[((size_t)b * A + head) * N + Np] = mx + __builtin_amdgcn_logf(ltot);
     __syncthreads();
     const int kg = tid >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -294,18 +299,20 @@ __global__ __launch_bounds__(256) void attn_cls_bf16_kernel(const bf16_t* __rest
 
 }  // namespace
 
-int launch_attention_bf16(const void* qkv, void* ctx, int B, int Np, int A, hipStream_t s) {
+int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_bf16: bad arguments");
     const dim3 grid((Np + QB - 1) / QB, A, B);
     if (Np % QB == 0)
-        hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, B, Np, A);
+        hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B, Np,
+                           A);
     else
-        hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, B, Np, A);
+        hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B, Np,
+                           A);
     VITSEG_LAUNCH_CHECK("attn_bf16");
     const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 16 * 64) * sizeof(float);
     VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_bf16: sequence too long for the CLS kernel");
-    hipLaunchKernelGGL(attn_cls_bf16_kernel, dim3(A, B), dim3(256), smem, s, (const bf16_t*)qkv, (bf16_t*)ctx, B, Np,
-                       A);
+    hipLaunchKernelGGL(attn_cls_bf16_kernel, dim3(A, B), dim3(256), smem, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B,
+                       Np, A);
     VITSEG_LAUNCH_CHECK("attn_cls_bf16");
     return VITSEG_OK;
 }

@@ -10,13 +10,18 @@ constexpr int MID = 256;
 
 // ---- column sums: out[n] = sum_m X[m][n]  (bias gradients) -----------------------------------
 // stage 1: block = 256 columns x a chunk of 256 rows -> partial[chunk][n]; stage 2: sum the chunks.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, float* __restrict__ partial,
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(*p); }
+
+template <typename InT>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const InT* __restrict__ X, float* __restrict__ partial,
                                                              int M, int N, int ld) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int r0 = blockIdx.y * 256, r1 = min(r0 + 256, M);
     if (n >= N) return;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += X[(size_t)r * ld + n];
+    for (int r = r0; r < r1; ++r) s += ldf(X + (size_t)r * ld + n);
     partial[(size_t)blockIdx.y * N + n] = s;
 }
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
@@ -34,9 +39,17 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 // dres_out[row] = (dres_in ? dres_in[row] : 0) + dx  (the residual branch's gradient is added here).
 // One wave per row (statistics recomputed from the saved input), 64 rows per block; the block's dw/db
 // partial sums go to partial[block][2][D].
-template <int NV>
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+    const uint2 u = *(const uint2*)p;
+    f32x4 r = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+               __uint_as_float(u.y & 0xffff0000u)};
+    return r;
+}
+
+template <int NV, typename GT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ g, const float* dres_in,
+                                                            const GT* __restrict__ g, const float* dres_in,
                                                             float* dres_out, float* __restrict__ partial, int rows,
                                                             int D, float eps) {
     __shared__ float red[2][4][NV * 256];
@@ -57,7 +70,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int i = 0; i < NV; ++i) {
             const int c = min(lane + 64 * i, nv - 1);
             xv[i] = ((const f32x4*)(x + (size_t)row * D))[c];
-            gv[i] = ((const f32x4*)(g + (size_t)row * D))[c];
+            gv[i] = ld4(g + (size_t)row * D + 4 * c);
         }
         float s = 0.f;
 #pragma unroll
@@ -226,7 +239,8 @@ __global__ __launch_bounds__(256) void head_bias_bwd_kernel(const float* __restr
 
 // ---- im2col materialisation for the two conv weight gradients (T-form B operands of the wgrad GEMM) ----
 // 3x3, pad 1 on the token-major map: T[m][tap*D + d] = H[(b, y+ky-1, x+kx-1)][d] or 0
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ H, float* __restrict__ T, int B, int g,
+template <typename HT>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const HT* __restrict__ H, float* __restrict__ T, int B, int g,
                                                         int D) {
     const int nv = D >> 2;
     const size_t total = (size_t)B * g * g * 9 * nv;
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if ((unsigned)yy < (unsigned)g && (unsigned)xx < (unsigned)g)
-            v = ((const f32x4*)(H + (m + (ptrdiff_t)(yy - y) * g + (xx - x)) * D))[dv];
+            v = ld4(H + (m + (ptrdiff_t)(yy - y) * g + (xx - x)) * D + 4 * dv);
         ((f32x4*)T)[i] = v;
     }
 }
@@ -303,28 +317,68 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// bf16 transpose with zero padding of the (new) contiguous dimension: out[c][r] = in[r][c], r < R; 0 for
+// R <= r < Rpad.  Feeds the bf16 weight-gradient GEMMs, whose reduction index (the token row) must be
+// contiguous and a multiple of 64.  64x64 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                             int R, int C, int ldin, int Rpad) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + i * 4 + ty, c = c0 + tx;
+        tile[i * 4 + ty][tx] = (r < R && c < C) ? in[(size_t)r * ldin + c] : (bf16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + i * 4 + ty, r = r0 + tx;
+        if (c < C && r < Rpad) out[(size_t)c * Rpad + r] = tile[tx][i * 4 + ty];
+    }
+}
+
 inline int grid_for(size_t n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
 
 }  // namespace
 
 size_t colsum_scratch_floats(int M, int N) { return (size_t)((M + 255) / 256) * N; }
-int launch_colsum(const float* X, float* out, float* scratch, int M, int N, int ld, hipStream_t s) {
+int launch_colsum(const void* X, int x_is_bf16, float* out, float* scratch, int M, int N, int ld, hipStream_t s) {
     const int chunks = (M + 255) / 256;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, s, X, scratch, M, N, ld);
+    if (x_is_bf16)
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3((N + 255) / 256, chunks), dim3(256), 0, s,
+                           (const bf16_t*)X, scratch, M, N, ld);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3((N + 255) / 256, chunks), dim3(256), 0, s,
+                           (const float*)X, scratch, M, N, ld);
     VITSEG_LAUNCH_CHECK("colsum_partial");
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, s, scratch, out, chunks, N);
     VITSEG_LAUNCH_CHECK("colsum_finish");
     return VITSEG_OK;
 }
 
+int launch_transpose_bf16(const void* in, void* out, int R, int C, int ldin, int Rpad, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (Rpad + 63) / 64), dim3(256), 0, s, (const bf16_t*)in,
+                       (bf16_t*)out, R, C, ldin, Rpad);
+    VITSEG_LAUNCH_CHECK("transpose_bf16");
+    return VITSEG_OK;
+}
+
 size_t layernorm_bwd_scratch_floats(int rows, int D) { return (size_t)((rows + 63) / 64) * 2 * D; }
-int launch_layernorm_bwd(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out, float* dw,
-                         float* db, float* scratch, int rows, int D, float eps, hipStream_t s) {
+int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is_bf16, const float* dres_in,
+                         float* dres_out, float* dw, float* db, float* scratch, int rows, int D, float eps,
+                         hipStream_t s) {
     VITSEG_CHECK_ARG(D % 4 == 0 && D <= 1024, VITSEG_ESHAPE, "layernorm_bwd: D=%d must be a multiple of 4, <= 1024", D);
     const int blocks = (rows + 63) / 64, nvl = (D / 4 + 63) / 64;
 #define VITSEG_LNB(NV)                                                                                            \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(blocks), dim3(256), 0, s, x, w, g, dres_in, dres_out,     \
-                       scratch, rows, D, eps)
+    do {                                                                                                          \
+        if (g_is_bf16)                                                                                            \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, bf16_t>), dim3(blocks), dim3(256), 0, s, x, w,           \
+                               (const bf16_t*)g, dres_in, dres_out, scratch, rows, D, eps);                       \
+        else                                                                                                      \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, float>), dim3(blocks), dim3(256), 0, s, x, w,            \
+                               (const float*)g, dres_in, dres_out, scratch, rows, D, eps);                        \
+    } while (0)
     if (nvl <= 1) VITSEG_LNB(1);
     else if (nvl <= 2) VITSEG_LNB(2);
     else if (nvl <= 3) VITSEG_LNB(3);
@@ -358,8 +412,12 @@ int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* 
     return VITSEG_OK;
 }
 
-int launch_im2col3x3(const float* H, float* T, int B, int g, int D, hipStream_t s) {
-    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for((size_t)B * g * g * 9 * (D / 4))), dim3(256), 0, s, H, T, B, g, D);
+int launch_im2col3x3(const void* H, int h_is_bf16, float* T, int B, int g, int D, hipStream_t s) {
+    const dim3 grid(grid_for((size_t)B * g * g * 9 * (D / 4)));
+    if (h_is_bf16)
+        hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)H, T, B, g, D);
+    else
+        hipLaunchKernelGGL(im2col3x3_kernel<float>, grid, dim3(256), 0, s, (const float*)H, T, B, g, D);
     VITSEG_LAUNCH_CHECK("im2col3x3");
     return VITSEG_OK;
 }

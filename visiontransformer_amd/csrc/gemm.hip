@@ -379,7 +379,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                 const int row = ps * RPP + rr;
                 const int grow = min(m0 + a_row0 + row, p.M - 1);
                 v[ps] = *(const f32x4*)&wl[row * 64 + c4];
-                if (EPI == EPI_RESADD || EPI == EPI_DGELU) extra[ps] = *(const f32x4*)(p.R + (size_t)grow * p.ldc + gcol);
+                if (EPI == EPI_RESADD || (EPI == EPI_DGELU && sizeof(T) == 4))
+                    extra[ps] = *(const f32x4*)(p.R + (size_t)grow * p.ldc + gcol);
+                if (EPI == EPI_DGELU && sizeof(T) == 2) {  // bf16 training: the saved pre-activation is bf16
+                    const uint2 u = *(const uint2*)((const bf16_t*)p.R + (size_t)grow * p.ldc + gcol);
+                    extra[ps][0] = __uint_as_float(u.x << 16);
+                    extra[ps][1] = __uint_as_float(u.x & 0xffff0000u);
+                    extra[ps][2] = __uint_as_float(u.y << 16);
+                    extra[ps][3] = __uint_as_float(u.y & 0xffff0000u);
+                }
                 if (EPI == EPI_POS) extra[ps] = *(const f32x4*)(p.R + (size_t)(1 + grow % p.Np) * p.N + gcol);
             }
 #pragma unroll
@@ -398,7 +406,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                     if (EPI == EPI_DGELU) x *= gelu_erf_grad(extra[ps][e]);
                     v[ps][e] = x;
                 }
-                if (EPI == EPI_GELU && p.aux) *(f32x4*)((float*)p.aux + o) = aux4;  // pre-activation, for backward
+                if (EPI == EPI_GELU && p.aux) {  // pre-activation, saved for the backward pass
+                    if constexpr (sizeof(OutT) == 4) {
+                        *(f32x4*)((float*)p.aux + o) = aux4;
+                    } else {
+                        uint2 h;
+                        h.x = pack2_bf16(aux4[0], aux4[1]);
+                        h.y = pack2_bf16(aux4[2], aux4[3]);
+                        *(uint2*)((bf16_t*)p.aux + o) = h;
+                    }
+                }
                 if constexpr (sizeof(OutT) == 4) {
                     *(f32x4*)(C + o) = v[ps];
                 } else {
@@ -826,6 +843,45 @@ int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     }
     set_error("gemm_bf16: unsupported amode/epilogue %d/%d", amode, epi);
     return VITSEG_EINVAL;
+}
+
+// bf16 training GEMMs (all N-form: dgrad multiplies by a transposed bf16 copy of the weight, wgrad by
+// transposed copies of dY and X whose reduction length is zero-padded to a multiple of 64).
+//   out_f32 = 0: C bf16, epi EPI_BIAS (plain dgrad), EPI_GELU (forward, `aux` = bf16 pre-activation) or
+//                EPI_DGELU (R = bf16 pre-activation);
+//   out_f32 = 1: C fp32, EPI_BIAS, optional split-K into `scratch` (weight gradients).
+int launch_gemm_bf16_train(GemmArgs a, int epi, int out_f32, float* scratch, hipStream_t s) {
+    VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 64 == 0, VITSEG_ESHAPE, "gemm_bf16_train: K=%d %% 64", a.K);
+    VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0 && a.lda % 8 == 0, VITSEG_ESHAPE, "gemm_bf16_train: alignment");
+    if (!out_f32) {
+        if (epi == EPI_BIAS) return launch_one<bf16_t, bf16_t, A_PLAIN, EPI_BIAS>(a, s);
+        if (epi == EPI_GELU) return launch_one<bf16_t, bf16_t, A_PLAIN, EPI_GELU>(a, s);
+        if (epi == EPI_DGELU) return launch_one<bf16_t, bf16_t, A_PLAIN, EPI_DGELU>(a, s);
+    } else if (epi == EPI_BIAS) {
+        const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+        int splits = (1024 + tiles - 1) / tiles;
+        if (splits > a.K / 64 / 4) splits = a.K / 64 / 4;
+        if (splits <= 1 || !scratch) return launch_one<bf16_t, float, A_PLAIN, EPI_BIAS>(a, s);
+        VITSEG_CHECK_ARG(a.ldc == a.N, VITSEG_EINVAL, "gemm_bf16_train: split-K needs a dense output");
+        float* out = (float*)a.C;
+        a.C = scratch;
+        a.splitk = splits;
+        a.split_stride = (size_t)a.M * a.N;
+        if (int rc = launch_one<bf16_t, float, A_PLAIN, EPI_BIAS>(a, s)) return rc;
+        const size_t n4 = (size_t)a.M * a.N / 4;
+        const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, scratch, out, n4, splits);
+        VITSEG_LAUNCH_CHECK("splitk_reduce");
+        return VITSEG_OK;
+    }
+    set_error("gemm_bf16_train: unsupported epilogue %d / out_f32 %d", epi, out_f32);
+    return VITSEG_EINVAL;
+}
+size_t wgrad_bf16_scratch_floats(int M, int N, int K) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int splits = (1024 + tiles - 1) / tiles;
+    if (splits > K / 64 / 4) splits = K / 64 / 4;
+    return (size_t)(splits < 1 ? 1 : splits) * M * N;
 }
 
 }  // namespace vitseg

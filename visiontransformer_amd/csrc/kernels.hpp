@@ -42,6 +42,8 @@ int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s);
 int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, hipStream_t s);
 size_t wgrad_scratch_floats(int M, int N, int K);
 int launch_wgrad_f32(GemmArgs a, float* scratch, hipStream_t s);
+int launch_gemm_bf16_train(GemmArgs a, int epi, int out_f32, float* scratch, hipStream_t s);
+size_t wgrad_bf16_scratch_floats(int M, int N, int K);
 int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s);
 
 // LayerNorm over the last dim (a4); out_bf16 selects the bf16-output variant.
@@ -54,7 +56,9 @@ int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np
 // dqkv[Mt,3D] from dctx[Mt,D]; dvec: scratch fp32 [B, A, Np+1]
 int launch_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dvec,
                              float* dqkv, int B, int Np, int A, hipStream_t s);
-int launch_attention_bf16(const void* qkv, void* ctx, int B, int Np, int A, hipStream_t s);
+int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, hipStream_t s);
+int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dvec,
+                              void* dqkv, int B, int Np, int A, hipStream_t s);
 
 // seg_head.2 (1x1 conv) on the ReLU'd mid features -> NCHW low-res logits (a11)
 int launch_head1x1(const float* F, const float* W2, const float* b2, float* Z, int B, int Np, int C, hipStream_t s);
@@ -73,15 +77,17 @@ int launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 
 // ---- backward pass (backward.hip) ----
 size_t colsum_scratch_floats(int M, int N);
-int launch_colsum(const float* X, float* out, float* scratch, int M, int N, int ld, hipStream_t s);
+int launch_colsum(const void* X, int x_is_bf16, float* out, float* scratch, int M, int N, int ld, hipStream_t s);
+int launch_transpose_bf16(const void* in, void* out, int R, int C, int ldin, int Rpad, hipStream_t s);
 size_t layernorm_bwd_scratch_floats(int rows, int D);
-int launch_layernorm_bwd(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out, float* dw,
-                         float* db, float* scratch, int rows, int D, float eps, hipStream_t s);
+int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is_bf16, const float* dres_in,
+                         float* dres_out, float* dw, float* db, float* scratch, int rows, int D, float eps,
+                         hipStream_t s);
 int launch_upsample_bwd(const float* G, float* dZ, int B, int C, int g, int S, hipStream_t s);
 size_t head1x1_bwd_scratch_floats(int B, int Np, int C);
 int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* dFpre, float* dW2, float* db2,
                        float* scratch, int B, int Np, int C, hipStream_t s);
-int launch_im2col3x3(const float* H, float* T, int B, int g, int D, hipStream_t s);
+int launch_im2col3x3(const void* H, int h_is_bf16, float* T, int B, int g, int D, hipStream_t s);
 int launch_im2col_patch(const float* img, float* T, int B, int Cin, int S, int P, hipStream_t s);
 int launch_conv_dgrad_weight(const float* W0, float* Wd, int D, hipStream_t s);
 int launch_embed_bwd(const float* dX, float* dpos, float* dcls, int B, int Np, int D, hipStream_t s);

@@ -230,7 +230,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         if ((rc = gemm(g, EPI_BIAS, VITSEG_K_GEMM_BIAS))) return rc;
         {
             ProfScope ps(VITSEG_K_ATTENTION, 4.0 * batch * s.A * (double)s.N * s.N * 64, st);
-            rc = lp ? launch_attention_bf16(QKV, H, batch, s.Np, s.A, st)
+            rc = lp ? launch_attention_bf16(QKV, H, nullptr, batch, s.Np, s.A, st)
                     : launch_attention_f32((const float*)QKV, (float*)H, nullptr, batch, s.Np, s.A, st);
             if (rc) return rc;
         }
@@ -361,11 +361,11 @@ int vitseg_op_attention_bwd_f32(const float* qkv, const float* dctx, float* ctx_
 
 int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out,
                                 float* dw, float* db, float* scratch, int rows, int D, float eps, void* stream) {
-    return launch_layernorm_bwd(x, w, g, dres_in, dres_out, dw, db, scratch, rows, D, eps, (hipStream_t)stream);
+    return launch_layernorm_bwd(x, w, g, 0, dres_in, dres_out, dw, db, scratch, rows, D, eps, (hipStream_t)stream);
 }
 
 int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream) {
-    return launch_attention_bf16(qkv, ctx, batch, num_patches, num_heads, (hipStream_t)stream);
+    return launch_attention_bf16(qkv, ctx, nullptr, batch, num_patches, num_heads, (hipStream_t)stream);
 }
 
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {

@@ -21,12 +21,17 @@ struct TrainPlan {
     LayerBufs lb;                 // offsets inside a layer block
     size_t xfinal, hf, f, z;      // after the last layer
     size_t dxa, dxb, dh, dqkv, du, dctx, dvec, g, dz, df, t, wd, scratch, wscratch, ce_partial, total;
+    // bf16 training only: bf16 copy of the fp32 residual gradient, transposed operands of the wgrad GEMMs
+    // ([rows][Kpad] with the token index contiguous), transposed weight for dgrad, zero page
+    size_t dxc, ta, tb, wt, zero, dhf, Kpad;
 };
 
-TrainPlan make_train_plan(const Shape& s, int B) {
+TrainPlan make_train_plan(const Shape& s, int B, int precision) {
     TrainPlan p{};
     p.Mp = (size_t)B * s.Np;
     p.Mt = p.Mp + B;
+    const bool lp = precision == VITSEG_BF16;
+    const size_t act = lp ? 2 : 4;  // bytes per element of the tensors that feed MFMAs
     const size_t MtD = p.Mt * s.D * 4, MtI = p.Mt * (size_t)s.I * 4;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -36,27 +41,27 @@ TrainPlan make_train_plan(const Shape& s, int B) {
     };
     // one layer block
     p.lb.xin = take(MtD);
-    p.lb.h1 = take(MtD);
-    p.lb.qkv = take(3 * MtD);
-    p.lb.ctx = take(MtD);
+    p.lb.h1 = take(MtD / 4 * act);
+    p.lb.qkv = take(3 * MtD / 4 * act);
+    p.lb.ctx = take(MtD / 4 * act);
     p.lb.lse = take((size_t)B * s.A * s.N * 4);
     p.lb.xmid = take(MtD);
-    p.lb.h2 = take(MtD);
-    p.lb.upre = take(MtI);
-    p.lb.uact = take(MtI);
+    p.lb.h2 = take(MtD / 4 * act);
+    p.lb.upre = take(MtI / 4 * act);
+    p.lb.uact = take(MtI / 4 * act);
     p.layer_stride = off;
     p.layer0 = 0;
     off = p.layer_stride * s.L;
     p.xfinal = take(MtD);
-    p.hf = take(p.Mp * s.D * 4);
+    p.hf = take(p.Mp * s.D * act);
     p.f = take(p.Mp * MID * 4);
     p.z = take((size_t)B * s.C * s.Np * 4);
     p.dxa = take(MtD);
     p.dxb = take(MtD);
-    p.dh = take(MtD);
-    p.dqkv = take(3 * MtD);
-    p.du = take(MtI);
-    p.dctx = take(MtD);
+    p.dh = take(MtD / 4 * act);
+    p.dqkv = take(3 * MtD / 4 * act);
+    p.du = take(MtI / 4 * act);
+    p.dctx = take(MtD / 4 * act);
     p.dvec = take((size_t)B * s.A * s.N * 4);
     p.g = take((size_t)B * s.C * s.S * s.S * 4);
     p.dz = take((size_t)B * s.C * s.Np * 4);
@@ -81,6 +86,24 @@ TrainPlan make_train_plan(const Shape& s, int B) {
         p.wscratch = take(w * 4);
     }
     p.ce_partial = take(ce_partial_count(B, s.S) * 8);
+    if (lp) {
+        p.Kpad = up(p.Mt, 64);
+        const size_t wide = (size_t)(s.I > 3 * s.D ? s.I : 3 * s.D);
+        p.dxc = take(p.Mt * s.D * 2);
+        p.dhf = take(p.Mp * s.D * 4);
+        p.ta = take(wide * p.Kpad * 2);
+        p.tb = take((size_t)(s.I > s.D ? s.I : s.D) * p.Kpad * 2);
+        p.wt = take(wide * s.D * 2);
+        p.zero = take(256);
+        size_t w = wgrad_bf16_scratch_floats(s.D, s.I, (int)p.Kpad);
+        auto mx = [&](size_t v) { w = v > w ? v : w; };
+        mx(wgrad_bf16_scratch_floats(s.I, s.D, (int)p.Kpad));
+        mx(wgrad_bf16_scratch_floats(s.D, s.D, (int)p.Kpad));
+        mx(wgrad_bf16_scratch_floats(3 * s.D, s.D, (int)p.Kpad));
+        mx(wgrad_scratch_floats(MID, 9 * s.D, (int)p.Mp));  // the head and patch wgrads stay fp32
+        mx(wgrad_scratch_floats(s.D, s.Kp, (int)p.Mp));
+        p.wscratch = take(w * 4);
+    }
     p.total = off;
     return p;
 }
@@ -94,6 +117,11 @@ struct Ctx {
     hipStream_t st;
     int B;
     float eps;
+    bool lp;
+    const unsigned short* params_lp;
+    const unsigned short* WL(int t, int l = 0) const { return params_lp + tensor_offset(lay, t, l); }
+    void* LV(int l, size_t off) const { return (void*)(ws + p.layer0 + (size_t)l * p.layer_stride + off); }
+    void* TV(size_t off) const { return (void*)(ws + off); }
     const float* W(int t, int l = 0) const { return params + tensor_offset(lay, t, l); }
     float* L(int l, size_t off) const { return (float*)(ws + p.layer0 + (size_t)l * p.layer_stride + off); }
     float* T(size_t off) const { return (float*)(ws + off); }
@@ -102,11 +130,11 @@ struct Ctx {
 int init_ctx(Ctx& c, const vitseg_config* cfg, const float* params, int B, int precision, void* ws, size_t ws_bytes,
              void* stream) {
     if (int rc = check_config(cfg, &c.s)) return rc;
-    VITSEG_CHECK_ARG(precision == VITSEG_F32, VITSEG_EINVAL, "training is implemented for VITSEG_F32 only (got %d)",
-                     precision);
+    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL, "precision %d", precision);
     VITSEG_CHECK_ARG(params && ws && B >= 1, VITSEG_EINVAL, "null pointer or batch < 1");
     VITSEG_CHECK_ARG(c.s.C <= 32, VITSEG_ESHAPE, "training supports at most 32 classes (got %d)", c.s.C);
-    c.p = make_train_plan(c.s, B);
+    c.p = make_train_plan(c.s, B, precision);
+    c.lp = precision == VITSEG_BF16;
     VITSEG_CHECK_ARG(ws_bytes >= c.p.total, VITSEG_EWORKSPACE, "training workspace %zu < required %zu", ws_bytes,
                      c.p.total);
     c.lay = make_layout(c.s);
@@ -126,6 +154,168 @@ GemmArgs lin(const void* A, const void* W, const float* bias, const float* R, vo
     return g;
 }
 
+
+// =========================================================================================================
+// Mixed-precision (bf16 operands, fp32 master weights / residual stream / gradients) training path.
+// All GEMMs are the N-form bf16 kernel: dgrad multiplies by a transposed bf16 copy of the weight, wgrad by
+// transposed copies of dY and X (token index contiguous, zero-padded to a multiple of 64), split-K, fp32 out.
+// The head (1.7 % of the FLOPs) and the patch embedding stay on the fp32 kernels.
+int forward_train_bf16(Ctx& c, const float* x, float* logits) {
+    const Shape& s = c.s;
+    const int Mt = (int)c.p.Mt, Mp = (int)c.p.Mp, D = s.D, I = s.I, batch = c.B;
+    hipStream_t st = c.st;
+    int rc;
+    {
+        float* X0 = c.L(0, c.p.lb.xin);
+        GemmArgs g = lin(x, c.W(VITSEG_T_PATCH_W), c.W(VITSEG_T_PATCH_B), c.W(VITSEG_T_POS), X0, Mp, D, s.Kp, 0, D);
+        g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
+        if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st))) return rc;
+        if ((rc = launch_cls_rows(c.W(VITSEG_T_CLS), c.W(VITSEG_T_POS), X0, batch, s.Np, D, st))) return rc;
+    }
+    for (int l = 0; l < s.L; ++l) {
+        float* Xin = c.L(l, c.p.lb.xin);
+        float* Xmid = c.L(l, c.p.lb.xmid);
+        float* Xout = l + 1 < s.L ? c.L(l + 1, c.p.lb.xin) : c.T(c.p.xfinal);
+        void *H1 = c.LV(l, c.p.lb.h1), *QKV = c.LV(l, c.p.lb.qkv), *CTX = c.LV(l, c.p.lb.ctx), *H2 = c.LV(l, c.p.lb.h2);
+        if ((rc = launch_layernorm(Xin, c.W(VITSEG_T_LN1_W, l), c.W(VITSEG_T_LN1_B, l), H1, Mt, D, c.eps, true, st)))
+            return rc;
+        GemmArgs g = lin(H1, c.WL(VITSEG_T_WQKV, l), c.W(VITSEG_T_BQKV, l), nullptr, QKV, Mt, 3 * D, D, D, 3 * D);
+        if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_BIAS, st))) return rc;
+        if ((rc = launch_attention_bf16(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, st))) return rc;
+        g = lin(CTX, c.WL(VITSEG_T_WO, l), c.W(VITSEG_T_BO, l), Xin, Xmid, Mt, D, D, D, D);
+        if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_RESADD, st))) return rc;
+        if ((rc = launch_layernorm(Xmid, c.W(VITSEG_T_LN2_W, l), c.W(VITSEG_T_LN2_B, l), H2, Mt, D, c.eps, true, st)))
+            return rc;
+        g = lin(H2, c.WL(VITSEG_T_W1, l), c.W(VITSEG_T_B1, l), nullptr, c.LV(l, c.p.lb.uact), Mt, I, D, D, I);
+        g.aux = c.LV(l, c.p.lb.upre);
+        if ((rc = launch_gemm_bf16_train(g, EPI_GELU, 0, nullptr, st))) return rc;
+        g = lin(c.LV(l, c.p.lb.uact), c.WL(VITSEG_T_W2, l), c.W(VITSEG_T_B2, l), Xmid, Xout, Mt, D, I, I, D);
+        if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_RESADD, st))) return rc;
+    }
+    void* Hf = c.TV(c.p.hf);
+    float* F = c.T(c.p.f);
+    float* Z = c.T(c.p.z);
+    if ((rc = launch_layernorm(c.T(c.p.xfinal), c.W(VITSEG_T_LNF_W), c.W(VITSEG_T_LNF_B), Hf, Mp, D, c.eps, true, st)))
+        return rc;
+    {
+        hipError_t e = hipMemsetAsync(c.ws + c.p.zero, 0, 256, st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(zero page)");
+        GemmArgs g = lin(Hf, c.WL(VITSEG_T_HEAD0_W), c.W(VITSEG_T_HEAD0_B), nullptr, F, Mp, MID, 9 * D, 0, MID);
+        g.g = s.g; g.Np = s.Np; g.D = D;
+        g.zeros = c.ws + c.p.zero;
+        if ((rc = launch_gemm_bf16(g, A_CONV3, EPI_RELU, st))) return rc;
+        if ((rc = launch_head1x1(F, c.W(VITSEG_T_HEAD2_W), c.W(VITSEG_T_HEAD2_B), Z, batch, s.Np, s.C, st))) return rc;
+    }
+    if (logits) return launch_upsample(Z, logits, nullptr, batch, s.C, s.g, s.S, st);
+    return VITSEG_OK;
+}
+
+int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, const float* grad_logits, float* grads,
+                  float* loss) {
+    const Shape& s = c.s;
+    const int Mt = (int)c.p.Mt, Mp = (int)c.p.Mp, D = s.D, I = s.I, B = c.B, Kpad = (int)c.p.Kpad;
+    hipStream_t st = c.st;
+    int rc;
+    auto G = [&](int t, int l = 0) { return grads + tensor_offset(c.lay, t, l); };
+    float* scratch = c.T(c.p.scratch);
+    float* wscr = c.T(c.p.wscratch);
+    void *tA = c.TV(c.p.ta), *tB = c.TV(c.p.tb), *wT = c.TV(c.p.wt), *dXc = c.TV(c.p.dxc);
+    {
+        hipError_t e = hipMemsetAsync(grads, 0, c.lay.total * sizeof(float), st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(grads)");
+    }
+    // dW[Nd,Kd] = dY[Mt,Nd]^T . X[Mt,Kd]  (both bf16, row-major) -> transposes + N-form split-K GEMM, fp32 out
+    auto wgrad = [&](const void* dY, const void* X, float* dW, int Nd, int Kd) {
+        int r;
+        if ((r = launch_transpose_bf16(dY, tA, Mt, Nd, Nd, Kpad, st))) return r;
+        if ((r = launch_transpose_bf16(X, tB, Mt, Kd, Kd, Kpad, st))) return r;
+        GemmArgs g = lin(tA, tB, nullptr, nullptr, dW, Nd, Kd, Kpad, Kpad, Kd);
+        g.ldw = Kpad;
+        return launch_gemm_bf16_train(g, EPI_BIAS, 1, wscr, st);
+    };
+    // dX[Mt,Kd] = dY[Mt,Nd] . W[Nd,Kd]  with W^T materialised as [Kd][Nd] bf16
+    auto dgrad = [&](const void* dY, const unsigned short* Wlp, void* dX, int Nd, int Kd, int epi, const void* R) {
+        int r;
+        if ((r = launch_transpose_bf16(Wlp, wT, Nd, Kd, Kd, Nd, st))) return r;
+        GemmArgs g = lin(dY, wT, nullptr, (const float*)R, dX, Mt, Kd, Nd, Nd, Kd);
+        g.ldw = Nd;
+        return launch_gemm_bf16_train(g, epi, 0, nullptr, st);
+    };
+
+    // ---- 1. loss -> d logits -> d low-res logits; 2. seg_head backward (fp32 kernels) ----
+    float* dZ = c.T(c.p.dz);
+    const float* Gfull = grad_logits;
+    if (target) {
+        if ((rc = launch_ce_loss(c.T(c.p.z), target, target_is_u8, c.T(c.p.g), (double*)(c.ws + c.p.ce_partial), loss, B,
+                                 s.C, s.g, s.S, st)))
+            return rc;
+        Gfull = c.T(c.p.g);
+    }
+    if ((rc = launch_upsample_bwd(Gfull, dZ, B, s.C, s.g, s.S, st))) return rc;
+    float* dF = c.T(c.p.df);
+    float* dHf = c.T(c.p.dhf);
+    if ((rc = launch_head1x1_bwd(dZ, c.T(c.p.f), c.W(VITSEG_T_HEAD2_W), dF, G(VITSEG_T_HEAD2_W), G(VITSEG_T_HEAD2_B),
+                                 scratch, B, s.Np, s.C, st)))
+        return rc;
+    if ((rc = launch_colsum(dF, 0, G(VITSEG_T_HEAD0_B), scratch, Mp, MID, MID, st))) return rc;
+    if ((rc = launch_im2col3x3(c.TV(c.p.hf), 1, c.T(c.p.t), B, s.g, D, st))) return rc;
+    {
+        GemmArgs g = lin(dF, c.T(c.p.t), nullptr, nullptr, G(VITSEG_T_HEAD0_W), MID, 9 * D, Mp, MID, 9 * D);
+        g.ldw = 9 * D;
+        if ((rc = launch_wgrad_f32(g, c.T(c.p.wscratch), st))) return rc;
+    }
+    if ((rc = launch_conv_dgrad_weight(c.W(VITSEG_T_HEAD0_W), c.T(c.p.wd), D, st))) return rc;
+    {
+        GemmArgs g = lin(dF, c.T(c.p.wd), nullptr, nullptr, dHf, Mp, D, 9 * MID, 0, D);
+        g.g = s.g; g.Np = s.Np; g.D = MID;
+        if ((rc = launch_gemm_f32_bwd(g, A_CONV3, 0, 0, EPI_BIAS, st))) return rc;
+    }
+    // ---- 3. final LayerNorm backward ----
+    float* dXa = c.T(c.p.dxa);
+    float* dXb = c.T(c.p.dxb);
+    {
+        hipError_t e = hipMemsetAsync(dXa + (size_t)Mp * D, 0, (size_t)(Mt - Mp) * D * sizeof(float), st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dX cls rows)");
+    }
+    if ((rc = launch_layernorm_bwd(c.T(c.p.xfinal), c.W(VITSEG_T_LNF_W), dHf, 0, nullptr, dXa, G(VITSEG_T_LNF_W),
+                                   G(VITSEG_T_LNF_B), scratch, Mp, D, c.eps, st)))
+        return rc;
+    // ---- 4. encoder layers ----
+    void *dH = c.TV(c.p.dh), *dU = c.TV(c.p.du), *dQKV = c.TV(c.p.dqkv), *dCTX = c.TV(c.p.dctx);
+    for (int l = s.L - 1; l >= 0; --l) {
+        if ((rc = launch_cast_bf16(dXa, dXc, (size_t)Mt * D, st))) return rc;
+        if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
+        if ((rc = wgrad(dXc, c.LV(l, c.p.lb.uact), G(VITSEG_T_W2, l), D, I))) return rc;
+        if ((rc = dgrad(dXc, c.WL(VITSEG_T_W2, l), dU, D, I, EPI_DGELU, c.LV(l, c.p.lb.upre)))) return rc;
+        if ((rc = launch_colsum(dU, 1, G(VITSEG_T_B1, l), scratch, Mt, I, I, st))) return rc;
+        if ((rc = wgrad(dU, c.LV(l, c.p.lb.h2), G(VITSEG_T_W1, l), I, D))) return rc;
+        if ((rc = dgrad(dU, c.WL(VITSEG_T_W1, l), dH, I, D, EPI_BIAS, nullptr))) return rc;
+        if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xmid), c.W(VITSEG_T_LN2_W, l), dH, 1, dXa, dXb, G(VITSEG_T_LN2_W, l),
+                                       G(VITSEG_T_LN2_B, l), scratch, Mt, D, c.eps, st)))
+            return rc;
+        if ((rc = launch_cast_bf16(dXb, dXc, (size_t)Mt * D, st))) return rc;
+        if ((rc = launch_colsum(dXb, 0, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
+        if ((rc = wgrad(dXc, c.LV(l, c.p.lb.ctx), G(VITSEG_T_WO, l), D, D))) return rc;
+        if ((rc = dgrad(dXc, c.WL(VITSEG_T_WO, l), dCTX, D, D, EPI_BIAS, nullptr))) return rc;
+        if ((rc = launch_attention_bwd_bf16(c.LV(l, c.p.lb.qkv), c.LV(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
+                                            c.T(c.p.dvec), dQKV, B, s.Np, s.A, st)))
+            return rc;
+        if ((rc = launch_colsum(dQKV, 1, G(VITSEG_T_BQKV, l), scratch, Mt, 3 * D, 3 * D, st))) return rc;
+        if ((rc = wgrad(dQKV, c.LV(l, c.p.lb.h1), G(VITSEG_T_WQKV, l), 3 * D, D))) return rc;
+        if ((rc = dgrad(dQKV, c.WL(VITSEG_T_WQKV, l), dH, 3 * D, D, EPI_BIAS, nullptr))) return rc;
+        if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xin), c.W(VITSEG_T_LN1_W, l), dH, 1, dXb, dXa, G(VITSEG_T_LN1_W, l),
+                                       G(VITSEG_T_LN1_B, l), scratch, Mt, D, c.eps, st)))
+            return rc;
+    }
+    // ---- 5. embeddings (fp32) ----
+    if ((rc = launch_embed_bwd(dXa, G(VITSEG_T_POS), G(VITSEG_T_CLS), B, s.Np, D, st))) return rc;
+    if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_PATCH_B), scratch, Mp, D, D, st))) return rc;
+    if ((rc = launch_im2col_patch(x, c.T(c.p.t), B, s.Cin, s.S, s.P, st))) return rc;
+    GemmArgs g = lin(dXa, c.T(c.p.t), nullptr, nullptr, G(VITSEG_T_PATCH_W), D, s.Kp, Mp, D, s.Kp);
+    g.ldw = s.Kp;
+    return launch_wgrad_f32(g, c.T(c.p.wscratch), st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -134,16 +324,20 @@ int vitseg_train_workspace(const vitseg_config* cfg, int batch, int precision, s
     Shape s;
     if (int rc = check_config(cfg, &s)) return rc;
     VITSEG_CHECK_ARG(batch >= 1 && bytes, VITSEG_EINVAL, "batch %d / null out pointer", batch);
-    VITSEG_CHECK_ARG(precision == VITSEG_F32, VITSEG_EINVAL, "training is implemented for VITSEG_F32 only");
-    *bytes = make_train_plan(s, batch).total;
+    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL, "precision %d", precision);
+    *bytes = make_train_plan(s, batch, precision).total;
     return VITSEG_OK;
 }
 
-int vitseg_forward_train(const vitseg_config* cfg, const float* params, const float* x, int batch, int precision,
-                         float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+int vitseg_forward_train(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x,
+                         int batch, int precision, float* logits, void* workspace, size_t workspace_bytes,
+                         void* stream) {
     Ctx c;
     if (int rc = init_ctx(c, cfg, params, batch, precision, workspace, workspace_bytes, stream)) return rc;
     VITSEG_CHECK_ARG(x, VITSEG_EINVAL, "x is null");
+    VITSEG_CHECK_ARG(!c.lp || params_bf16, VITSEG_EINVAL, "bf16 training needs the bf16 arena");
+    c.params_lp = (const unsigned short*)params_bf16;
+    if (c.lp) return forward_train_bf16(c, x, logits);
     const Shape& s = c.s;
     const int Mt = (int)c.p.Mt, Mp = (int)c.p.Mp, D = s.D, I = s.I;
     hipStream_t st = c.st;
@@ -194,12 +388,15 @@ int vitseg_forward_train(const vitseg_config* cfg, const float* params, const fl
     return VITSEG_OK;
 }
 
-int vitseg_backward(const vitseg_config* cfg, const float* params, const float* x, int batch, int precision,
-                    const void* target, int target_is_u8, const float* grad_logits, float* grads, float* loss,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+int vitseg_backward(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x, int batch,
+                    int precision, const void* target, int target_is_u8, const float* grad_logits, float* grads,
+                    float* loss, void* workspace, size_t workspace_bytes, void* stream) {
     Ctx c;
     if (int rc = init_ctx(c, cfg, params, batch, precision, workspace, workspace_bytes, stream)) return rc;
     VITSEG_CHECK_ARG(x && grads, VITSEG_EINVAL, "x / grads is null");
+    VITSEG_CHECK_ARG(!c.lp || params_bf16, VITSEG_EINVAL, "bf16 training needs the bf16 arena");
+    c.params_lp = (const unsigned short*)params_bf16;
+    if (c.lp) return backward_bf16(c, x, target, target_is_u8, grad_logits, grads, loss);
     VITSEG_CHECK_ARG((target != nullptr) != (grad_logits != nullptr), VITSEG_EINVAL,
                      "pass exactly one of target (fused CE) and grad_logits");
     VITSEG_CHECK_ARG(!target || loss, VITSEG_EINVAL, "fused CE needs the loss output pointer");
@@ -244,8 +441,8 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const float* 
     if ((rc = launch_head1x1_bwd(dZ, c.T(c.p.f), c.W(VITSEG_T_HEAD2_W), dF, G(VITSEG_T_HEAD2_W), G(VITSEG_T_HEAD2_B),
                                  scratch, B, s.Np, s.C, st)))
         return rc;
-    if ((rc = launch_colsum(dF, G(VITSEG_T_HEAD0_B), scratch, Mp, MID, MID, st))) return rc;
-    if ((rc = launch_im2col3x3(Hf, c.T(c.p.t), B, s.g, D, st))) return rc;
+    if ((rc = launch_colsum(dF, 0, G(VITSEG_T_HEAD0_B), scratch, Mp, MID, MID, st))) return rc;
+    if ((rc = launch_im2col3x3(Hf, 0, c.T(c.p.t), B, s.g, D, st))) return rc;
     if ((rc = wgrad(dF, c.T(c.p.t), G(VITSEG_T_HEAD0_W), Mp, MID, 9 * D))) return rc;
     if ((rc = launch_conv_dgrad_weight(c.W(VITSEG_T_HEAD0_W), c.T(c.p.wd), D, st))) return rc;
     {
@@ -260,7 +457,7 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const float* 
         hipError_t e = hipMemsetAsync(dXa + (size_t)Mp * D, 0, (size_t)(Mt - Mp) * D * sizeof(float), st);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dX cls rows)");
     }
-    if ((rc = launch_layernorm_bwd(c.T(c.p.xfinal), c.W(VITSEG_T_LNF_W), dH, nullptr, dXa, G(VITSEG_T_LNF_W),
+    if ((rc = launch_layernorm_bwd(c.T(c.p.xfinal), c.W(VITSEG_T_LNF_W), dH, 0, nullptr, dXa, G(VITSEG_T_LNF_W),
                                    G(VITSEG_T_LNF_B), scratch, Mp, D, c.eps, st)))
         return rc;
 
@@ -270,32 +467,32 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const float* 
     float* dCTX = c.T(c.p.dctx);
     for (int l = s.L - 1; l >= 0; --l) {
         // MLP: Xout = Xmid + fc2(gelu(fc1(H2)))
-        if ((rc = launch_colsum(dXa, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
+        if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
         if ((rc = wgrad(dXa, c.L(l, c.p.lb.uact), G(VITSEG_T_W2, l), Mt, D, I))) return rc;
         if ((rc = dgrad(dXa, c.W(VITSEG_T_W2, l), dU, Mt, D, I, EPI_DGELU, c.L(l, c.p.lb.upre)))) return rc;
-        if ((rc = launch_colsum(dU, G(VITSEG_T_B1, l), scratch, Mt, I, I, st))) return rc;
+        if ((rc = launch_colsum(dU, 0, G(VITSEG_T_B1, l), scratch, Mt, I, I, st))) return rc;
         if ((rc = wgrad(dU, c.L(l, c.p.lb.h2), G(VITSEG_T_W1, l), Mt, I, D))) return rc;
         if ((rc = dgrad(dU, c.W(VITSEG_T_W1, l), dH, Mt, I, D, EPI_BIAS, nullptr))) return rc;
-        if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xmid), c.W(VITSEG_T_LN2_W, l), dH, dXa, dXb, G(VITSEG_T_LN2_W, l),
+        if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xmid), c.W(VITSEG_T_LN2_W, l), dH, 0, dXa, dXb, G(VITSEG_T_LN2_W, l),
                                        G(VITSEG_T_LN2_B, l), scratch, Mt, D, c.eps, st)))
             return rc;
         // attention: Xmid = Xin + o_proj(attn(qkv(H1)))
-        if ((rc = launch_colsum(dXb, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
+        if ((rc = launch_colsum(dXb, 0, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
         if ((rc = wgrad(dXb, c.L(l, c.p.lb.ctx), G(VITSEG_T_WO, l), Mt, D, D))) return rc;
         if ((rc = dgrad(dXb, c.W(VITSEG_T_WO, l), dCTX, Mt, D, D, EPI_BIAS, nullptr))) return rc;
         if ((rc = launch_attention_bwd_f32(c.L(l, c.p.lb.qkv), c.L(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
                                            c.T(c.p.dvec), dQKV, B, s.Np, s.A, st)))
             return rc;
-        if ((rc = launch_colsum(dQKV, G(VITSEG_T_BQKV, l), scratch, Mt, 3 * D, 3 * D, st))) return rc;
+        if ((rc = launch_colsum(dQKV, 0, G(VITSEG_T_BQKV, l), scratch, Mt, 3 * D, 3 * D, st))) return rc;
         if ((rc = wgrad(dQKV, c.L(l, c.p.lb.h1), G(VITSEG_T_WQKV, l), Mt, 3 * D, D))) return rc;
         if ((rc = dgrad(dQKV, c.W(VITSEG_T_WQKV, l), dH, Mt, 3 * D, D, EPI_BIAS, nullptr))) return rc;
-        if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xin), c.W(VITSEG_T_LN1_W, l), dH, dXb, dXa, G(VITSEG_T_LN1_W, l),
+        if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xin), c.W(VITSEG_T_LN1_W, l), dH, 0, dXb, dXa, G(VITSEG_T_LN1_W, l),
                                        G(VITSEG_T_LN1_B, l), scratch, Mt, D, c.eps, st)))
             return rc;
     }
     // ---- 5. embeddings ----
     if ((rc = launch_embed_bwd(dXa, G(VITSEG_T_POS), G(VITSEG_T_CLS), B, s.Np, D, st))) return rc;
-    if ((rc = launch_colsum(dXa, G(VITSEG_T_PATCH_B), scratch, Mp, D, D, st))) return rc;
+    if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_PATCH_B), scratch, Mp, D, D, st))) return rc;
     if ((rc = launch_im2col_patch(x, c.T(c.p.t), B, s.Cin, s.S, s.P, st))) return rc;
     return wgrad(dXa, c.T(c.p.t), G(VITSEG_T_PATCH_W), Mp, D, s.Kp);
 }

@@ -196,9 +196,7 @@ class ViTSegmentationModel(nn.Module):
         key = ("train", batch)
         ws = self._ws.get(key)
         if ws is None:
-            if self.precision != _lib.F32:
-                raise NotImplementedError("training through libvitseg is built for precision='fp32' only")
-            ws = torch.empty(_lib.train_workspace(self.cfg, batch, _lib.F32), dtype=torch.uint8,
+            ws = torch.empty(_lib.train_workspace(self.cfg, batch, self.precision), dtype=torch.uint8,
                              device=self.arena.device)
             self._ws = {key: ws}
         return ws
@@ -212,8 +210,9 @@ class ViTSegmentationModel(nn.Module):
             if want_logits else None
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().vitseg_forward_train(
-                C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(), x.data_ptr(), B, _lib.F32,
-                _ptr(logits), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+                C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(), _ptr(self._bf16_arena()),
+                x.data_ptr(), B, self.precision, _ptr(logits), ws.data_ptr(), ws.numel(),
+                torch.cuda.current_stream().cuda_stream))
         return logits
 
     def _backward(self, x: torch.Tensor, target: Optional[torch.Tensor] = None,
@@ -225,7 +224,8 @@ class ViTSegmentationModel(nn.Module):
         loss = torch.zeros((), dtype=torch.float32, device=x.device) if target is not None else None
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().vitseg_backward(
-                C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(), x.data_ptr(), B, _lib.F32,
+                C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(), _ptr(self._bf16_arena()),
+                x.data_ptr(), B, self.precision,
                 _ptr(target), int(target is not None and target.dtype == torch.uint8), _ptr(grad_logits),
                 grads.data_ptr(), _ptr(loss), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
         return grads, loss
