@@ -13,32 +13,6 @@ constexpr int MID = 256;
 typedef unsigned short bf16_t;
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(*p); }
-
-template <typename InT>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const InT* __restrict__ X, float* __restrict__ partial,
-                                                             int M, int N, int ld) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * 256, r1 = min(r0 + 256, M);
-    if (n >= N) return;
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += ldf(X + (size_t)r * ld + n);
-    partial[(size_t)blockIdx.y * N + n] = s;
-}
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                            int chunks, int N) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * N + n];
-    out[n] = s;
-}
-
-// ---- LayerNorm backward ------------------------------------------------------------------------
-// y = xhat * w + b, xhat = (x - mu) * rstd.  With gw = g * w:
-//   dx = rstd * (gw - mean(gw) - xhat * mean(gw * xhat));   dw = sum_rows g * xhat;   db = sum_rows g.
-// dres_out[row] = (dres_in ? dres_in[row] : 0) + dx  (the residual branch's gradient is added here).
-// One wave per row (statistics recomputed from the saved input), 64 rows per block; the block's dw/db
-// partial sums go to partial[block][2][D].
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
     const uint2 u = *(const uint2*)p;
@@ -47,6 +21,54 @@ __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
     return r;
 }
 
+// Block = 256 rows x 256 columns: wave w sums rows r0 + 64 w .. + 63, lane owns 4 adjacent columns (one 8- or
+// 16-byte load per row), the 4 waves are combined through LDS in a fixed order.
+template <typename InT>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const InT* __restrict__ X, float* __restrict__ partial,
+                                                             int M, int N, int ld) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 256 + lane * 4;
+    const int r0 = blockIdx.y * 256 + wave * 64, r1 = min(r0 + 64, M);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (n + 3 < N) {
+        for (int r = r0; r < r1; ++r) {
+            const f32x4 v = ld4(X + (size_t)r * ld + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        }
+    } else {
+        for (int r = r0; r < r1; ++r)
+            for (int e = 0; e < 4; ++e)
+                if (n + e < N) acc[e] += ldf(X + (size_t)r * ld + n + e);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = acc[e];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < N)
+        partial[(size_t)blockIdx.y * N + c] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// out[n] = sum_chunks partial[chunk][n]: block = 64 columns x 4 chunk groups, combined through LDS
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int chunks, int N) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float s = 0.f;
+    if (col < N)
+        for (int c = grp; c < chunks; c += 4) s += partial[(size_t)c * N + col];
+    red[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && col < N) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- LayerNorm backward ------------------------------------------------------------------------
+// y = xhat * w + b, xhat = (x - mu) * rstd.  With gw = g * w:
+//   dx = rstd * (gw - mean(gw) - xhat * mean(gw * xhat));   dw = sum_rows g * xhat;   db = sum_rows g.
+// dres_out[row] = (dres_in ? dres_in[row] : 0) + dx  (the residual branch's gradient is added here).
+// One wave per row (statistics recomputed from the saved input), 64 rows per block; the block's dw/db
+// partial sums go to partial[block][2][D].
 template <int NV, typename GT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const GT* __restrict__ g, const float* dres_in,
@@ -134,18 +156,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         partial[((size_t)blockIdx.x * 2 + 1) * D + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
     }
 }
-// partial[block][2][D] -> dw[D], db[D]
+// partial[block][2][D] -> dw[D], db[D]: block = 64 columns of the 2D-wide matrix x 4 block groups
 __global__ __launch_bounds__(256) void layernorm_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                                    float* __restrict__ db, int blocks, int D) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < blocks; ++k) {
-        a += partial[((size_t)k * 2 + 0) * D + c];
-        b += partial[((size_t)k * 2 + 1) * D + c];
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;  // col in [0, 2D)
+    float s = 0.f;
+    if (col < 2 * D)
+        for (int k = grp; k < blocks; k += 4) s += partial[(size_t)k * 2 * D + col];
+    red[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && col < 2 * D) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (col < D) dw[col] = v; else db[col - D] = v;
     }
-    dw[c] = a;
-    db[c] = b;
 }
 
 // ---- transposed bilinear upsample: G[B,C,S,S] -> dZ[B,C,g,g] -----------------------------------
@@ -352,7 +376,7 @@ int launch_colsum(const void* X, int x_is_bf16, float* out, float* scratch, int 
         hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3((N + 255) / 256, chunks), dim3(256), 0, s,
                            (const float*)X, scratch, M, N, ld);
     VITSEG_LAUNCH_CHECK("colsum_partial");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, s, scratch, out, chunks, N);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, s, scratch, out, chunks, N);
     VITSEG_LAUNCH_CHECK("colsum_finish");
     return VITSEG_OK;
 }
@@ -385,7 +409,7 @@ int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is
     else VITSEG_LNB(4);
 #undef VITSEG_LNB
     VITSEG_LAUNCH_CHECK("layernorm_bwd");
-    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, s, scratch, dw, db, blocks, D);
+    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, scratch, dw, db, blocks, D);
     VITSEG_LAUNCH_CHECK("layernorm_bwd_finish");
     return VITSEG_OK;
 }
@@ -405,7 +429,7 @@ int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* 
     hipLaunchKernelGGL(head1x1_bwd_kernel, dim3(blocks), dim3(256), 0, s, dZ, F, W2, dFpre, scratch, B, Np, C);
     VITSEG_LAUNCH_CHECK("head1x1_bwd");
     // scratch is [blocks][C*256]: column sums over the blocks
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C * MID + 255) / 256), dim3(256), 0, s, scratch, dW2, blocks, C * MID);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C * MID + 63) / 64), dim3(256), 0, s, scratch, dW2, blocks, C * MID);
     VITSEG_LAUNCH_CHECK("head1x1_bwd_finish");
     hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(C), dim3(256), 0, s, dZ, db2, B, Np, C);
     VITSEG_LAUNCH_CHECK("head_bias_bwd");
