@@ -845,6 +845,147 @@ int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     return VITSEG_EINVAL;
 }
 
+// =====================================================================================================
+// bf16 weight-gradient GEMM with BOTH operands in T-form:  C[M,N] = sum_k A[k][M-index] * W[k][N-index]
+// (dW = dY^T X: A = dY [tokens][M], W = X [tokens][N], the reduction runs over the token rows).  No
+// transposed copies: a K step stages 64 token rows x 128 columns of each operand as they lie in memory
+// ([64][128] bf16, 256-B rows, global_load_lds) and the MFMA operands are gathered DOWN the columns with
+// ds_read_b64_tr_b16 (4 tokens x 16 columns per 16-lane group).  Both operands use the same k permutation
+// (element j of lane half h = token 16s + 8(j>>2) + 4h + (j&3)), so the products pair up correctly.
+// 16-byte chunk c of row r is stored at c ^ ((r & 3) << 2): the 4 rows x 2 column blocks of one transposed
+// read then hit 16 distinct 16-byte slots of the 256-B bank row.  Split-K over grid.y, fp32 partial output.
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tt_kernel(const GemmArgs p) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][64 * 128];  // [buffer][A|W][token][column]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = t / tiles_n, tile_n = t - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int KT_all = (p.K + 63) / 64;
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const int kt0 = (int)((long long)KT_all * split / nsplit);
+    const int KT = (int)((long long)KT_all * (split + 1) / nsplit) - kt0;
+
+    // DMA: per operand 16 pieces of 1 KiB (4 token rows x 256 B) per K step; wave w issues pieces 4w .. 4w+3.
+    // lane l -> row l >> 4, chunk position l & 15 holding logical chunk (l & 15) ^ ((row & 3) << 2).
+    const int drow = lane >> 4;
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave * 4 + i) * 4 + drow;  // token row inside the tile, 0..63
+            const int ch = (lane & 15) ^ ((r & 3) << 2);
+            const int tok = (kt + kt0) * 64 + r;
+            const bool ok = tok < p.K;
+            const int ca = min(m0 + ch * 8, p.M - 8), cw = min(n0 + ch * 8, p.N - 8);  // clamped: never stored
+            const bf16_t* ga = ok ? (const bf16_t*)p.A + (size_t)tok * p.lda + ca : (const bf16_t*)p.zeros;
+            const bf16_t* gw = ok ? (const bf16_t*)p.W + (size_t)tok * p.ldw + cw : (const bf16_t*)p.zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                             (__attribute__((address_space(3))) void*)&lds[buf][0][(wave * 4 + i) * 4 * 128],
+                                             16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
+                                             (__attribute__((address_space(3))) void*)&lds[buf][1][(wave * 4 + i) * 4 * 128],
+                                             16, 0, 0);
+        }
+    };
+    // transposed fragment: tokens t0 .. t0+15 (lane half h: t0 + 4h + {0..3} and + 8), column col0 + (lane & 31)
+    const int g = lane & 15, grp = lane >> 4, tq = g >> 2, tp = g & 3;
+    auto tr_frag = [&](const bf16_t* tile, int t0, int col0) {
+        const int row = t0 + 4 * (grp >> 1) + tq;
+        const int col = col0 + 16 * (grp & 1) + 4 * tp;
+        const int off0 = row * 128 + ((((col >> 3) ^ ((row & 3) << 2)) << 3) | (col & 7));
+        const int off1 = (row + 8) * 128 + ((((col >> 3) ^ (((row + 8) & 3) << 2)) << 3) | (col & 7));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off1));
+        const bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return f;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if (KT > 0) issue(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // step kt is in LDS for every wave; buffer buf^1 is no longer read
+        if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = tr_frag(lds[buf][0], 16 * s, wm * 64 + mi * 32);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = tr_frag(lds[buf][1], 16 * s, wn * 64 + ni * 32);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: fp32 partial tile, staged through LDS for row-vector stores ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int li = lane & 31, lh = lane >> 5;
+    float* wl = (float*)&lds[0][0][0] + wave * 4096;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                wl[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + ni * 32 + li] = acc[mi][ni][r];
+    const int rr = lane >> 4, c4 = (lane & 15) * 4;
+    const int gcol = n0 + wn * 64 + c4;
+    float* C = (float*)p.C + (size_t)blockIdx.y * p.split_stride;
+    f32x4 v[16];
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) v[ps] = *(const f32x4*)&wl[(ps * 4 + rr) * 64 + c4];
+    if (gcol >= p.N) return;
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+        const int grow = m0 + wm * 64 + ps * 4 + rr;
+        if (grow < p.M) *(f32x4*)(C + (size_t)grow * p.ldc + gcol) = v[ps];
+    }
+}
+
+// dW[M,N] (fp32, dense) = A^T . W with A = [K][M], W = [K][N] bf16 row-major; split-K through `scratch`.
+int launch_wgrad_bf16_tt(GemmArgs a, float* scratch, hipStream_t s) {
+    VITSEG_CHECK_ARG(a.M % 8 == 0 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc == a.N && a.zeros,
+                     VITSEG_ESHAPE, "wgrad_bf16_tt: M, N and the leading dimensions must be multiples of 8");
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    int splits = (1024 + tiles - 1) / tiles;
+    const int ksteps = (a.K + 63) / 64;
+    if (splits > ksteps / 4) splits = ksteps / 4;
+    if (splits < 1) splits = 1;
+    float* out = (float*)a.C;
+    if (splits > 1) {
+        VITSEG_CHECK_ARG(scratch, VITSEG_EINVAL, "wgrad_bf16_tt: split-K needs scratch");
+        a.C = scratch;
+    }
+    a.split_stride = (size_t)a.M * a.N;
+    hipLaunchKernelGGL(gemm_bf16_tt_kernel<0>, dim3(tiles, splits), dim3(256), 0, s, a);
+    VITSEG_LAUNCH_CHECK("gemm_bf16_tt");
+    if (splits > 1) {
+        const size_t n4 = (size_t)a.M * a.N / 4;
+        const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, scratch, out, n4, splits);
+        VITSEG_LAUNCH_CHECK("splitk_reduce");
+    }
+    return VITSEG_OK;
+}
+
 // bf16 training GEMMs (all N-form: dgrad multiplies by a transposed bf16 copy of the weight, wgrad by
 // transposed copies of dY and X whose reduction length is zero-padded to a multiple of 64).
 //   out_f32 = 0: C bf16, epi EPI_BIAS (plain dgrad), EPI_GELU (forward, `aux` = bf16 pre-activation) or

@@ -42,6 +42,7 @@ int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s);
 int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, hipStream_t s);
 size_t wgrad_scratch_floats(int M, int N, int K);
 int launch_wgrad_f32(GemmArgs a, float* scratch, hipStream_t s);
+int launch_wgrad_bf16_tt(GemmArgs a, float* scratch, hipStream_t s);
 int launch_gemm_bf16_train(GemmArgs a, int epi, int out_f32, float* scratch, hipStream_t s);
 size_t wgrad_bf16_scratch_floats(int M, int N, int K);
 int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s);

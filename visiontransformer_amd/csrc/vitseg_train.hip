@@ -226,13 +226,12 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
     }
     // dW[Nd,Kd] = dY[Mt,Nd]^T . X[Mt,Kd]  (both bf16, row-major) -> transposes + N-form split-K GEMM, fp32 out
     auto wgrad = [&](const void* dY, const void* X, float* dW, int Nd, int Kd) {
-        int r;
-        if ((r = launch_transpose_bf16(dY, tA, Mt, Nd, Nd, Kpad, st))) return r;
-        if ((r = launch_transpose_bf16(X, tB, Mt, Kd, Kd, Kpad, st))) return r;
-        GemmArgs g = lin(tA, tB, nullptr, nullptr, dW, Nd, Kd, Kpad, Kpad, Kd);
-        g.ldw = Kpad;
-        return launch_gemm_bf16_train(g, EPI_BIAS, 1, wscr, st);
+        GemmArgs g = lin(dY, X, nullptr, nullptr, dW, Nd, Kd, Mt, Nd, Kd);  // both operands T-form, no copies
+        g.ldw = Kd;
+        g.zeros = c.ws + c.p.zero;
+        return launch_wgrad_bf16_tt(g, wscr, st);
     };
+    (void)tA; (void)tB; (void)Kpad;
     // dX[Mt,Kd] = dY[Mt,Nd] . W[Nd,Kd]  with W^T materialised as [Kd][Nd] bf16
     auto dgrad = [&](const void* dY, const unsigned short* Wlp, void* dX, int Nd, int Kd, int epi, const void* R) {
         int r;
