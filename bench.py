@@ -228,6 +228,12 @@ def main():
                             "achieved_tflops_per_gpu": round(value / world * flops_img / 1e12, 2),
                             "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
+            # the HBM-bound pieces against the 8 TB/s roof (algorithmic bytes / hipEvent time, same timed region)
+            "roofline_hbm": {k: {"achieved_GBps": round(prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e9, 1),
+                                 "peak_GBps": 8000.0,
+                                 "frac": round(prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 8e12, 4),
+                                 "bytes_per_launch": prof[k]["work"] / max(prof[k]["launches"], 1)}
+                             for k in ("layernorm", "upsample") if prof[k]["ms"] > 0},
         }
         if args.precision == "f32" and not args.no_cpu_baseline:
             # informational: the same step on the bf16-operand path (outside the timed region, rank 0 only)

@@ -130,3 +130,31 @@ def test_ce_loss_matches_reference(name):
     ref = O.ce_loss(O.forward(x.double(), {k: v.double() for k, v in sd.items()}, cfg), t)
     got = m.ce_loss(x.to(DEV), t.to(torch.uint8).to(DEV))
     assert abs(float(got) - float(ref)) < 5e-6
+
+
+def test_vit_large_width_tiled_1024():
+    """BASELINE configs[4] shape family: ViT-L/16 width (D=1024, A=16; 2 layers here), 1024x1024 inputs as four
+    512x512 tiles through an image_size=512 model, bf16 operands (the build's half-precision path; fp16 is not
+    built).  Checked against the oracle run tile by tile."""
+    cfg = ViTSegConfig(2, 16, 1024, 2, 16, image_size=512)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=51).items()}
+    big = torch.from_numpy(synth.uniform01(9, "big", 3 * 1024 * 1024).reshape(1, 3, 1024, 1024).astype(np.float32))
+    m = ViTSegmentationModel(2, 16, 1024, 2, 16, image_size=512, precision="bf16", device=DEV).eval()
+    m.load_state_dict(sd)
+    mask = m.predict_mask_tiled(big.to(DEV)).cpu()
+    assert mask.shape == (1, 1024, 1024)
+    with torch.no_grad():
+        for ty in range(2):
+            for tx in range(2):
+                tile = big[:, :, ty * 512:(ty + 1) * 512, tx * 512:(tx + 1) * 512]
+                ref = O.forward(tile, sd, cfg)
+                srt = ref.sort(dim=1, descending=True).values
+                solid = (srt[:, 0] - srt[:, 1]) > 2e-2  # bf16 logits are good to ~5e-3
+                got = mask[:, ty * 512:(ty + 1) * 512, tx * 512:(tx + 1) * 512].long()
+                assert bool((got == O.predict_mask(ref))[solid].all())
+    # fp32 path accepts the wide model too
+    m32 = ViTSegmentationModel(2, 16, 1024, 2, 16, image_size=512, device=DEV).eval()
+    m32.load_state_dict(sd)
+    with torch.no_grad():
+        lg = m32(big[:, :, :512, :512].to(DEV))
+        assert (lg.cpu() - O.forward(big[:, :, :512, :512], sd, cfg)).abs().max().item() < 1e-3

@@ -249,6 +249,21 @@ class ViTSegmentationModel(nn.Module):
         logits, mask = self._run(x, return_logits, True)
         return (mask, logits) if return_logits else mask
 
+    @torch.no_grad()
+    def predict_mask_tiled(self, x: torch.Tensor) -> torch.Tensor:
+        """Masks for images LARGER than the model's image size by spatial tiling (BASELINE configs[4]: 1024x1024
+        inputs through an image_size=512 model as four 512x512 tiles per image; build-defined).
+        x: [B, 3, H, W] with H, W multiples of image_size -> uint8 [B, H, W].  Tiles are independent units, so they
+        simply extend the batch; each tile sees only its own pixels (no cross-tile attention)."""
+        S = self.cfg.image_size
+        B, Cc, H, W = x.shape
+        if H % S or W % S:
+            raise ValueError(f"tiled prediction needs H and W to be multiples of {S}, got {H}x{W}")
+        ty, tx = H // S, W // S
+        tiles = x.reshape(B, Cc, ty, S, tx, S).permute(0, 2, 4, 1, 3, 5).reshape(B * ty * tx, Cc, S, S).contiguous()
+        m = self.predict_mask(tiles)
+        return m.reshape(B, ty, tx, S, S).permute(0, 1, 3, 2, 4).reshape(B, H, W).contiguous()
+
     def ce_loss(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """`nn.CrossEntropyLoss()(self(x), target)` (model/CE/classes.py:268,280) as a device scalar, without
         materialising the [B, C, S, S] logits: forward to the low-res map, then the fused upsample+CE kernel.
