@@ -36,15 +36,16 @@ from visiontransformer_amd.model import ViTSegmentationModel  # noqa: E402
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
 KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
-    "f32": {"gemm_bias": "gemm_kernel<float, float, 0, 0>", "gemm_gelu": "gemm_kernel<float, float, 0, 1>",
-            "gemm_resadd": "gemm_kernel<float, float, 0, 2>", "gemm_patch": "gemm_kernel<float, float, 1, 4>",
-            "gemm_conv3": "gemm_kernel<float, float, 2, 3>",
+    "f32": {"gemm_bias": "gemm_kernel<float, float, 0, 0, 0, 0>", "gemm_gelu": "gemm_kernel<float, float, 0, 1, 0, 0>",
+            "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0>",
+            "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0>",
             "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
-    "bf16": {"gemm_bias": "gemm_kernel<unsigned short, unsigned short, 0, 0>",
-             "gemm_gelu": "gemm_kernel<unsigned short, unsigned short, 0, 1>",
-             "gemm_resadd": "gemm_kernel<unsigned short, float, 0, 2>",
-             "gemm_patch": "gemm_kernel<float, float, 1, 4>",
-             "gemm_conv3": "gemm_kernel<unsigned short, float, 2, 3>",
+    "bf16": {"gemm_bias": "gemm_kernel<unsigned short, unsigned short, 0, 0, 0, 0>",
+             "gemm_gelu": "gemm_kernel<unsigned short, unsigned short, 0, 1, 0, 0>",
+             "gemm_resadd": "gemm_kernel<unsigned short, float, 0, 2, 0, 0> (o_proj) + "
+                            "gemm_bf16_large_kernel<float, 0, 2> (fc2)",
+             "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0>",
+             "gemm_conv3": "gemm_kernel<unsigned short, float, 2, 3, 0, 0>",
              "attention": "attn_bf16_kernel<false> + attn_cls_bf16_kernel"},
 }
 

@@ -60,9 +60,20 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e) taps(4 * xq + e, scale, g, x0[e], x1[e], wx0[e], wx1[e]);
 
-    float best[4];
+    // argmax_c sigmoid(v_c) with first-index ties.  sigmoid is monotone, so the answer is the raw argmax m unless
+    // an EARLIER class rounds to the same fp32 sigmoid.  That cannot happen when the top-1 logit t1 has
+    // |t1| <= 8 and leads every other class by >= 4e-3: sigma' >= 3.3e-4 on [t1 - 4e-3, t1], so the true
+    // sigmoids differ by >= 1.3e-6 ~ 22 ulp(1), far beyond the <= 2 ulp error of 1/(1+exp(-x)).  Only the
+    // remaining (near-tie or saturated) pixels evaluate the exact fp32 sigmoids; the result is identical.
+    float t1[4], t2[4];
     int arg[4];
-    for (int c = 0; c < C; ++c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        t1[e] = -INFINITY;
+        t2[e] = -INFINITY;
+        arg[e] = 0;
+    }
+    auto logit4 = [&](int c) {
         const float* zt = Z + (((size_t)b * C + c) * g + y0) * g;
         const float* zb = Z + (((size_t)b * C + c) * g + y1) * g;
         f32x4 v;
@@ -72,20 +83,42 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
             const float bot = __fmaf_rn(zb[x0[e]], wx0[e], __fmul_rn(zb[x1[e]], wx1[e]));
             v[e] = __fmaf_rn(top, wy0, __fmul_rn(bot, wy1));
         }
+        return v;
+    };
+    for (int c = 0; c < C; ++c) {
+        const f32x4 v = logit4(c);
         if (logits) *(f32x4*)(logits + (((size_t)b * C + c) * S + Y) * S + 4 * xq) = v;
         if (mask) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                // torch CPU sigmoid: 1 / (1 + exp(-x)), then argmax keeps the FIRST maximal class
-                const float sg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v[e])));
-                if (c == 0 || sg > best[e]) {
-                    best[e] = sg;
+                if (v[e] > t1[e]) {  // strict: the first maximal class stays
+                    t2[e] = t1[e];
+                    t1[e] = v[e];
                     arg[e] = c;
+                } else {
+                    t2[e] = fmaxf(t2[e], v[e]);
                 }
             }
         }
     }
     if (mask) {
+        bool amb = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amb = amb || !(fabsf(t1[e]) <= 8.0f && t1[e] - t2[e] >= 4e-3f);
+        if (amb) {  // exact path: torch CPU sigmoid 1 / (1 + exp(-x)), first maximal class wins
+            float best[4];
+            for (int c = 0; c < C; ++c) {
+                const f32x4 v = logit4(c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v[e])));
+                    if (c == 0 || sg > best[e]) {
+                        best[e] = sg;
+                        arg[e] = c;
+                    }
+                }
+            }
+        }
         uchar4 m4;
         m4.x = (unsigned char)arg[0];
         m4.y = (unsigned char)arg[1];
