@@ -520,22 +520,29 @@ int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s) {
 // `s_waitcnt vmcnt(6)`: the 6 DMA pieces of step kt+1 may stay outstanding) two compute phases later.
 // M = B*Np + B: the B*Np patch rows are whole 256-row tiles at 512x512; the CLS rows make one thin tile
 // that is scheduled first and in which only the first wave row computes.
-constexpr int LBM = 256, LBN = 128, LSTAGES = 3;
+constexpr int LBM = 256;
 
-template <typename OutT, int AMODE, int EPI>
+// LBN = 128: waves 4(M) x 2(N), 64x64 per wave, 3-stage ring (3 x 48 KiB), 85 FLOP per staged byte.
+// LBN = 256: waves 2(M) x 4(N), 128x64 per wave (128 accumulator registers), 2-stage ring (2 x 64 KiB),
+//            128 FLOP per staged byte -- half the L2->LDS traffic of the 128x128 kernel, which is what bounds it.
+template <typename OutT, int AMODE, int EPI, int LBN>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs p) {
     typedef bf16_t T;
     constexpr int CE = 8, BKE = 64, BK = BKF;
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [stage][A 256 rows | W 128 rows][32 words]
+    constexpr int STAGES = LBN == 128 ? 3 : 2;
+    constexpr int MI = LBN == 128 ? 2 : 4, NI = 2;      // 32x32 MFMA tiles per wave
+    constexpr int WROWS = MI * 32;                       // rows per wave
+    constexpr int WPW = LBN / 64;                        // W DMA pieces per wave (8 rows each)
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [stage][A 256 rows | W LBN rows][32 words]
     auto stageA = [&](int st) { return lds_raw + st * (LBM + LBN) * BK; };
     auto stageW = [&](int st) { return lds_raw + st * (LBM + LBN) * BK + LBM * BK; };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches below
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = LBN == 128 ? wave >> 1 : wave >> 2, wn = LBN == 128 ? wave & 1 : wave & 3;
     const int tiles_n = (p.N + LBN - 1) / LBN, tiles_m = (p.M + LBM - 1) / LBM;
     int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int GN = (size_t)p.K * sizeof(T) <= 2048 ? 8 : 4;
+    const int GN = LBN == 128 ? ((size_t)p.K * sizeof(T) <= 2048 ? 8 : 4) : 4;
     const bool thin_last = p.M - (tiles_m - 1) * LBM <= 64 && tiles_m > 1;
     int tile_m, tile_n;
     if (thin_last && t < tiles_n) {
@@ -554,10 +561,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
     const int m0 = tile_m * LBM, n0 = tile_n * LBN;
     const bool computes = (p.M - m0 > 64) || wm == 0;  // thin tile: only the first 64 rows exist
 
-    // ---- DMA assignment: per K step 32 A pieces + 16 W pieces of 1 KiB (8 rows each); wave w issues
-    //      A pieces w*4 .. w*4+3 and W pieces w*2, w*2+1 ----
+    // ---- DMA assignment: per K step 32 A pieces + LBN/8 W pieces of 1 KiB (8 rows each) ----
     const T* asrc[4];
-    const T* wsrc[2];
+    const T* wsrc[WPW];
     int ay[4], ax[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -575,8 +581,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < WPW; ++i) {
+        const int row = (wave * WPW + i) * 8 + (lane >> 3);
         const int cpos = (lane & 7) ^ ((row >> 1) & 7);
         wsrc[i] = (const T*)p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + cpos * CE;
     }
@@ -604,158 +610,162 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
                                              16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WPW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(stageW(st) + (wave * 2 + i) * 8 * BK),
+                                             (__attribute__((address_space(3))) void*)(stageW(st) + (wave * WPW + i) * 8 * BK),
                                              16, 0, 0);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     const int li = lane & 31, lh = lane >> 5;
     const int sw = (li >> 1) & 7;
-    const int a_off = (wm * 64 + li) * BK, b_off = (wn * 64 + li) * BK;
-    f32x4 a[2][2], b[2][2];
+    const int a_off = (wm * WROWS + li) * BK, b_off = (wn * 64 + li) * BK;
+    f32x4 a[2][MI], b[2][NI];
     auto lfrag = [&](int st, int j, int slot) {
         const int ch = (((2 * j + lh) ^ sw) << 2);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) a[slot][mi] = *(const f32x4*)&stageA(st)[a_off + mi * 32 * BK + ch];
+        for (int mi = 0; mi < MI; ++mi) a[slot][mi] = *(const f32x4*)&stageA(st)[a_off + mi * 32 * BK + ch];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) b[slot][ni] = *(const f32x4*)&stageW(st)[b_off + ni * 32 * BK + ch];
+        for (int ni = 0; ni < NI; ++ni) b[slot][ni] = *(const f32x4*)&stageW(st)[b_off + ni * 32 * BK + ch];
     };
-    auto mfma4 = [&](int slot) {
+    auto mfmas = [&](int slot) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[slot][mi]),
                                                                       __builtin_bit_cast(bf16x8, b[slot][ni]),
                                                                       acc[mi][ni], 0, 0, 0);
     };
 
     const int KT = p.K / BKE;
-    // 3-stage ring: while step kt is computed, steps kt+1 and kt+2 are in flight.  The loop is rotated around
-    // the barrier (group 3 of step kt runs after the barrier that publishes step kt+1, under the first
-    // fragment reads of step kt+1) and sched_barrier pins "next group's ds_reads, then this group's MFMAs".
+    // Ring of STAGES buffers: while step kt is computed, steps kt+1 .. kt+STAGES-2 are in flight.  The loop is
+    // rotated around the barrier (group 3 of step kt runs after the barrier that publishes step kt+1, under the
+    // first fragment reads of step kt+1); sched_barrier pins "next group's ds_reads, then this group's MFMAs".
     issue(0, 0);
-    if (KT > 1) issue(1, 1);
-    if (KT > 2) issue(2, 2);
-    if (KT > 2)
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (KT > 1)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (STAGES == 3 && KT > 1) issue(1, 1);
+    if (STAGES == 3 && KT > 1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // 6 = DMA pieces per wave per step at LBN = 128
     else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (STAGES == 2 && KT > 1) issue(1, 1);
+    if (STAGES == 3 && KT > 2) issue(2, 2);
     int st = 0;
     if (computes) lfrag(0, 0, 0);
     for (int kt = 0; kt < KT; ++kt) {
-        const int stn = st == 2 ? 0 : st + 1;
+        const int stn = st == STAGES - 1 ? 0 : st + 1;
         if (computes) {
             lfrag(st, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mfma4(0);
+            mfmas(0);
             __builtin_amdgcn_sched_barrier(0);
             lfrag(st, 2, 0);
             __builtin_amdgcn_sched_barrier(0);
-            mfma4(1);
+            mfmas(1);
             __builtin_amdgcn_sched_barrier(0);
             lfrag(st, 3, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mfma4(0);
+            mfmas(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (kt + 1 < KT) {
-            // step kt+1 has landed once at most the 6 pieces of step kt+2 are outstanding (in-order retire);
+            // step kt+1 has landed once only the pieces of later steps are outstanding (in-order retire);
             // lgkmcnt(0): this wave's reads of stage st are complete before anyone refills it
-            if (kt + 2 < KT)
+            if (STAGES == 3 && kt + 2 < KT)
                 asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 3 < KT) issue(kt + 3, st);
+            if (kt + STAGES < KT) issue(kt + STAGES, st);
             if (computes) {
                 lfrag(stn, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (computes) mfma4(1);
+        if (computes) mfmas(1);
         st = stn;
     }
 
-    // ---- epilogue: per-wave LDS staging, row-vector stores (same scheme as the 128x128 kernel) ----
+    // ---- epilogue: per-wave LDS staging (16 KiB = 64 rows x 64 cols fp32 at a time), row-vector stores ----
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (!computes) return;
     float* wl = lds_raw + wave * 4096;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                wl[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + ni * 32 + li] = acc[mi][ni][r];
     const int rr = lane >> 4, c4 = (lane & 15) * 4;
     const int gcol = n0 + wn * 64 + c4;
-    if (gcol >= p.N) return;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias4 = *(const f32x4*)(p.bias + gcol);
+    if (p.bias && gcol < p.N) bias4 = *(const f32x4*)(p.bias + gcol);
     OutT* C = (OutT*)p.C;
-    // all LDS reads (and residual loads) first, stores last: in a kernel that contains LDS-DMA hipcc waits
-    // vmcnt(0) before every use of a ds_read result, which would serialise the stores one by one
-    f32x4 v[16], extra[16];
 #pragma unroll
-    for (int ps = 0; ps < 16; ++ps) {
-        const int row = ps * 4 + rr;
-        v[ps] = *(const f32x4*)&wl[row * 64 + c4];
-        if (EPI == EPI_RESADD) {
-            const int grow = min(m0 + wm * 64 + row, p.M - 1);
-            extra[ps] = *(const f32x4*)(p.R + (size_t)grow * p.ldc + gcol);
-        }
-    }
+    for (int half = 0; half < MI / 2; ++half) {
 #pragma unroll
-    for (int ps = 0; ps < 16; ++ps) {
-        const int grow = m0 + wm * 64 + ps * 4 + rr;
-        const size_t o = (size_t)grow * p.ldc + gcol;
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = v[ps][e] + bias4[e];
-            if (EPI == EPI_GELU) x = gelu_erf_fast(x);
-            if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
-            if (EPI == EPI_RESADD) x = extra[ps][e] + x;
-            v[ps][e] = x;
-        }
-        if (grow < p.M) {
-            if constexpr (sizeof(OutT) == 4) {
-                *(f32x4*)(C + o) = v[ps];
-            } else {
-                uint2 h;
-                h.x = pack2_bf16(v[ps][0], v[ps][1]);
-                h.y = pack2_bf16(v[ps][2], v[ps][3]);
-                *(uint2*)(C + o) = h;
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wl[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + ni * 32 + li] = acc[half * 2 + mi][ni][r];
+        // all LDS reads (and residual loads) first, stores last: in a kernel that contains LDS-DMA hipcc waits
+        // vmcnt(0) before every use of a ds_read result, which would serialise the stores one by one
+        f32x4 v[16], extra[16];
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            const int row = ps * 4 + rr;
+            v[ps] = *(const f32x4*)&wl[row * 64 + c4];
+            if (EPI == EPI_RESADD) {
+                const int grow = min(m0 + wm * WROWS + half * 64 + row, p.M - 1);
+                extra[ps] = *(const f32x4*)(p.R + (size_t)grow * p.ldc + min(gcol, p.N - 4));
             }
         }
+        if (gcol < p.N) {
+#pragma unroll
+            for (int ps = 0; ps < 16; ++ps) {
+                const int grow = m0 + wm * WROWS + half * 64 + ps * 4 + rr;
+                const size_t o = (size_t)grow * p.ldc + gcol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[ps][e] + bias4[e];
+                    if (EPI == EPI_GELU) x = gelu_erf_fast(x);
+                    if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
+                    if (EPI == EPI_RESADD) x = extra[ps][e] + x;
+                    v[ps][e] = x;
+                }
+                if (grow < p.M) {
+                    if constexpr (sizeof(OutT) == 4) {
+                        *(f32x4*)(C + o) = v[ps];
+                    } else {
+                        uint2 h;
+                        h.x = pack2_bf16(v[ps][0], v[ps][1]);
+                        h.y = pack2_bf16(v[ps][2], v[ps][3]);
+                        *(uint2*)(C + o) = h;
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private buffer is reused by the next half
     }
 }
 
-template <typename OutT, int AMODE, int EPI>
+template <typename OutT, int AMODE, int EPI, int LBN = 128>
 int launch_large(GemmArgs a, hipStream_t s) {
     if (a.ldw == 0) a.ldw = a.K;
     const int tiles = ((a.M + LBM - 1) / LBM) * ((a.N + LBN - 1) / LBN);
-    const size_t smem = (size_t)LSTAGES * (LBM + LBN) * BKF * sizeof(float);  // 144 KiB
+    const size_t smem = (size_t)(LBN == 128 ? 3 : 2) * (LBM + LBN) * BKF * sizeof(float);  // 144 / 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_large_kernel<OutT, AMODE, EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_large_kernel<OutT, AMODE, EPI, LBN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_large)");
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_large_kernel<OutT, AMODE, EPI>), dim3(tiles), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((gemm_bf16_large_kernel<OutT, AMODE, EPI, LBN>), dim3(tiles), dim3(512), smem, s, a);
     VITSEG_LAUNCH_CHECK("gemm_bf16_large");
     return VITSEG_OK;
 }
@@ -825,17 +835,21 @@ int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
                      a.ldc);
     // the 256x128 / 3-stage kernel and the 128x128 / 2-stage kernel measure within a few % of each other on the
     // model's shapes (both ~790 TF/s asymptote); the large one is used where its deeper prefetch helps: long K
-    const char* force = getenv("VITSEG_BF16_TILES");  // "large" / "small" for experiments
-    const bool large = force ? force[0] == 'l' : (a.M >= 4096 && a.K >= 2048);
+    const char* force = getenv("VITSEG_BF16_TILES");  // "large" / "xl" / "small" for experiments
+    const bool xl = force ? force[0] == 'x' : (a.M >= 8192 && a.N >= 2048);
+    const bool large = force ? force[0] == 'l' : (!xl && a.M >= 4096 && a.K >= 2048);
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 8 == 0, VITSEG_EINVAL, "gemm_bf16: lda %% 8");
         switch (epi) {
-            case EPI_BIAS: return large ? launch_large<bf16_t, A_PLAIN, EPI_BIAS>(a, s)
-                                        : launch_one<bf16_t, bf16_t, A_PLAIN, EPI_BIAS>(a, s);
-            case EPI_GELU: return large ? launch_large<bf16_t, A_PLAIN, EPI_GELU>(a, s)
-                                        : launch_one<bf16_t, bf16_t, A_PLAIN, EPI_GELU>(a, s);
-            case EPI_RESADD: return large ? launch_large<float, A_PLAIN, EPI_RESADD>(a, s)
-                                          : launch_one<bf16_t, float, A_PLAIN, EPI_RESADD>(a, s);
+            case EPI_BIAS: return xl ? launch_large<bf16_t, A_PLAIN, EPI_BIAS, 256>(a, s)
+                                  : large ? launch_large<bf16_t, A_PLAIN, EPI_BIAS>(a, s)
+                                          : launch_one<bf16_t, bf16_t, A_PLAIN, EPI_BIAS>(a, s);
+            case EPI_GELU: return xl ? launch_large<bf16_t, A_PLAIN, EPI_GELU, 256>(a, s)
+                                  : large ? launch_large<bf16_t, A_PLAIN, EPI_GELU>(a, s)
+                                          : launch_one<bf16_t, bf16_t, A_PLAIN, EPI_GELU>(a, s);
+            case EPI_RESADD: return xl ? launch_large<float, A_PLAIN, EPI_RESADD, 256>(a, s)
+                                    : large ? launch_large<float, A_PLAIN, EPI_RESADD>(a, s)
+                                            : launch_one<bf16_t, float, A_PLAIN, EPI_RESADD>(a, s);
         }
     } else if (amode == A_CONV3 && epi == EPI_RELU) {
         VITSEG_CHECK_ARG(a.D % 64 == 0 && a.zeros, VITSEG_ESHAPE, "hidden size must be a multiple of 64");
