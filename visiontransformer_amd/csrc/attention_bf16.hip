@@ -152,16 +152,23 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
                 for (int r = 0; r < 16; ++r)
                     if (kt * KB + kb * 32 + kappa(r, lh) >= Np) st[kb][r] = -INFINITY;
         }
-        float mx = st[0][0];
+        float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+        for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, st[0][r]), st[1][r]);  // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        m_run = m_new;
-        const float mc = m_new * c;
+        // the running maximum settles after the first few key tiles: rescale O and l only when some lane's
+        // maximum actually grew (wave-uniform branch), otherwise alpha == 1 exactly and the work is skipped
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * c;
         float psum = 0.f;
         unsigned pk[2][8];  // P^T fragments: pk[kb][4 s + w] = registers 8 s + 2 w, 8 s + 2 w + 1
 #pragma unroll
@@ -173,11 +180,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
                 psum += p0 + p1;
                 pk[kb][r >> 1] = pack_bf16(p0, p1);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        l_run += psum;
 
         // O^T[d][query] += V^T[d][key] . P^T[key][query]
 #pragma unroll
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 }
 
 // The B*A CLS queries: one block per (head, image); plain VALU in fp32 on bf16 inputs.
-__global__ __launch_bounds__(256) void attn_cls_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+__global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                             float* __restrict__ lse, int B, int Np, int A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int N = Np + 1;
@@ -242,30 +245,41 @@ __global__ __launch_bounds__(256) void attn_cls_bf16_kernel(const bf16_t* __rest
     const uint2 qu = *(const uint2*)(qp + 4 * sub);
     const float qs = 0.125f * LOG2E;
     const float q0 = bf_lo(qu.x) * qs, q1 = bf_hi(qu.x) * qs, q2 = bf_lo(qu.y) * qs, q3 = bf_hi(qu.y) * qs;
-    for (int base = wave * 4; base < N; base += 16) {
-        const int key = base + grp;
-        float part = 0.f;
-        if (key < N) {
-            const size_t row = key < Np ? row0 + key : cls_row;
-            const uint2 ku = *(const uint2*)(kbase + row * ld + 4 * sub);
-            part = q0 * bf_lo(ku.x) + q1 * bf_hi(ku.x) + q2 * bf_lo(ku.y) + q3 * bf_hi(ku.y);
+    // 4 keys per 16-lane group and iteration: four independent row loads in flight (the loop is latency-bound)
+    for (int base = wave * 4; base < N; base += 256) {
+        float part[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = base + 64 * u + grp;
+            part[u] = 0.f;
+            if (key < N) {
+                const size_t row = key < Np ? row0 + key : cls_row;
+                const uint2 ku = *(const uint2*)(kbase + row * ld + 4 * sub);
+                part[u] = q0 * bf_lo(ku.x) + q1 * bf_hi(ku.x) + q2 * bf_lo(ku.y) + q3 * bf_hi(ku.y);
+            }
         }
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
-        part += __shfl_xor(part, 8, 64);
-        if (sub == 0 && key < N) sc[key] = part;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float pu = part[u];
+            pu += __shfl_xor(pu, 1, 64);
+            pu += __shfl_xor(pu, 2, 64);
+            pu += __shfl_xor(pu, 4, 64);
+            pu += __shfl_xor(pu, 8, 64);
+            const int key = base + 64 * u + grp;
+            if (sub == 0 && key < N) sc[key] = pu;
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
-    for (int i = tid; i < N; i += 256) mx = fmaxf(mx, sc[i]);
+    for (int i = tid; i < N; i += 1024) mx = fmaxf(mx, sc[i]);
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
     __syncthreads();
     float sum = 0.f;
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += 1024) {
         const float pv = __builtin_amdgcn_exp2f(sc[i] - mx);
         sc[i] = pv;
         sum += pv;
@@ -273,26 +287,36 @@ __global__ __launch_bounds__(256) void attn_cls_bf16_kernel(const bf16_t* __rest
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
-    const float ltot = red[0] + red[1] + red[2] + red[3];
+    float ltot = 0.f;
+    for (int w = 0; w < 16; ++w) ltot += red[w];
     const float inv = 1.0f / ltot;
     if (lse && tid == 0) lse[((size_t)b * A + head) * N + Np] = mx + __builtin_amdgcn_logf(ltot);
     __syncthreads();
     const int kg = tid >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int key = kg; key < N; key += 16) {
-        const size_t row = key < Np ? row0 + key : cls_row;
-        const uint2 vu = *(const uint2*)(vbase + row * ld + 4 * sub);
-        const float pv = sc[key];
-        acc[0] = fmaf(pv, bf_lo(vu.x), acc[0]);
-        acc[1] = fmaf(pv, bf_hi(vu.x), acc[1]);
-        acc[2] = fmaf(pv, bf_lo(vu.y), acc[2]);
-        acc[3] = fmaf(pv, bf_hi(vu.y), acc[3]);
+    for (int key0 = kg; key0 < N; key0 += 256) {
+        uint2 vu[4];
+        float pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = min(key0 + 64 * u, N - 1);
+            const size_t row = key < Np ? row0 + key : cls_row;
+            vu[u] = *(const uint2*)(vbase + row * ld + 4 * sub);
+            pv[u] = key0 + 64 * u < N ? sc[key] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] = fmaf(pv[u], bf_lo(vu[u].x), acc[0]);
+            acc[1] = fmaf(pv[u], bf_hi(vu[u].x), acc[1]);
+            acc[2] = fmaf(pv[u], bf_lo(vu[u].y), acc[2]);
+            acc[3] = fmaf(pv[u], bf_hi(vu[u].y), acc[3]);
+        }
     }
     *(f32x4*)&red[kg * 64 + 4 * sub] = acc;
     __syncthreads();
     if (tid < 64) {
         float s = 0.f;
-        for (int gI = 0; gI < 16; ++gI) s += red[gI * 64 + tid];
+        for (int gI = 0; gI < 64; ++gI) s += red[gI * 64 + tid];
         ctx[cls_row * (size_t)D + head * HD + tid] = f32_to_bf16(s * inv);
     }
 }
@@ -309,9 +333,9 @@ int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np,
         hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B, Np,
                            A);
     VITSEG_LAUNCH_CHECK("attn_bf16");
-    const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 16 * 64) * sizeof(float);
+    const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 64 * 64) * sizeof(float);
     VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_bf16: sequence too long for the CLS kernel");
-    hipLaunchKernelGGL(attn_cls_bf16_kernel, dim3(A, B), dim3(256), smem, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B,
+    hipLaunchKernelGGL(attn_cls_bf16_kernel, dim3(A, B), dim3(1024), smem, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B,
                        Np, A);
     VITSEG_LAUNCH_CHECK("attn_cls_bf16");
     return VITSEG_OK;

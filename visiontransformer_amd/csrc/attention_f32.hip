@@ -200,12 +200,12 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
 }
 
 // The B*A CLS queries: one block per (head, image); plain VALU (1 x N x 64 per block).
-__global__ __launch_bounds__(256) void attn_cls_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+__global__ __launch_bounds__(1024) void attn_cls_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                            float* __restrict__ lse, int B, int Np, int A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // scores[N] then reduce scratch
     const int N = Np + 1;
     float* sc = sm;
-    float* red = sm + ((N + 63) & ~63);  // 16 groups x 64 floats
+    float* red = sm + ((N + 63) & ~63);  // 64 key groups x 64 floats
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.x, b = blockIdx.y;
     const int D = A * HD, ld = 3 * D;
@@ -218,30 +218,41 @@ __global__ __launch_bounds__(256) void attn_cls_f32_kernel(const float* __restri
     f32x4 q4 = *(const f32x4*)(qp + 4 * sub);
     const float qs = 0.125f * LOG2E;
     for (int e = 0; e < 4; ++e) q4[e] *= qs;
-    for (int base = wave * 4; base < N; base += 16) {
-        const int key = base + grp;
-        float part = 0.f;
-        if (key < N) {
-            const size_t row = key < Np ? row0 + key : cls_row;
-            const f32x4 k4 = *(const f32x4*)(kbase + row * ld + 4 * sub);
-            part = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+    // 4 keys per 16-lane group and iteration: four independent row loads in flight (the loop is latency-bound)
+    for (int base = wave * 4; base < N; base += 256) {
+        float part[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = base + 64 * u + grp;
+            part[u] = 0.f;
+            if (key < N) {
+                const size_t row = key < Np ? row0 + key : cls_row;
+                const f32x4 k4 = *(const f32x4*)(kbase + row * ld + 4 * sub);
+                part[u] = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+            }
         }
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
-        part += __shfl_xor(part, 8, 64);
-        if (sub == 0 && key < N) sc[key] = part;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float pu = part[u];
+            pu += __shfl_xor(pu, 1, 64);
+            pu += __shfl_xor(pu, 2, 64);
+            pu += __shfl_xor(pu, 4, 64);
+            pu += __shfl_xor(pu, 8, 64);
+            const int key = base + 64 * u + grp;
+            if (sub == 0 && key < N) sc[key] = pu;
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
-    for (int i = tid; i < N; i += 256) mx = fmaxf(mx, sc[i]);
+    for (int i = tid; i < N; i += 1024) mx = fmaxf(mx, sc[i]);
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
     __syncthreads();
     float sum = 0.f;
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += 1024) {
         const float pv = __builtin_amdgcn_exp2f(sc[i] - mx);
         sc[i] = pv;
         sum += pv;
@@ -249,24 +260,33 @@ __global__ __launch_bounds__(256) void attn_cls_f32_kernel(const float* __restri
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
-    const float ltot = red[0] + red[1] + red[2] + red[3];
+    float ltot = 0.f;
+    for (int w = 0; w < 16; ++w) ltot += red[w];
     const float inv = 1.0f / ltot;
     if (lse && tid == 0) lse[((size_t)b * A + head) * N + Np] = mx + __builtin_amdgcn_logf(ltot);
     __syncthreads();
     // out[d] = sum_key p[key] V[key][d]: thread = (key group kg of 16, 4-float chunk sub)
     const int kg = tid >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int key = kg; key < N; key += 16) {
-        const size_t row = key < Np ? row0 + key : cls_row;
-        const f32x4 v4 = *(const f32x4*)(vbase + row * ld + 4 * sub);
-        const float pv = sc[key];
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(pv, v4[e], acc[e]);
+    for (int key0 = kg; key0 < N; key0 += 256) {
+        f32x4 v4[4];
+        float pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = min(key0 + 64 * u, N - 1);
+            const size_t row = key < Np ? row0 + key : cls_row;
+            v4[u] = *(const f32x4*)(vbase + row * ld + 4 * sub);
+            pv[u] = key0 + 64 * u < N ? sc[key] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(pv[u], v4[u][e], acc[e]);
     }
     *(f32x4*)&red[kg * 64 + 4 * sub] = acc;
     __syncthreads();
     if (tid < 64) {
         float s = 0.f;
-        for (int g = 0; g < 16; ++g) s += red[g * 64 + tid];
+        for (int g = 0; g < 64; ++g) s += red[g * 64 + tid];
         ctx[cls_row * (size_t)D + head * HD + tid] = s * inv;
     }
 }
@@ -281,9 +301,9 @@ int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np
     else
         hipLaunchKernelGGL(attn_f32_kernel<true>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A);
     VITSEG_LAUNCH_CHECK("attn_f32");
-    const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 16 * 64) * sizeof(float);
+    const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 64 * 64) * sizeof(float);
     VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_f32: sequence too long for the CLS kernel");
-    hipLaunchKernelGGL(attn_cls_f32_kernel, dim3(A, B), dim3(256), smem, s, qkv, ctx, lse, B, Np, A);
+    hipLaunchKernelGGL(attn_cls_f32_kernel, dim3(A, B), dim3(1024), smem, s, qkv, ctx, lse, B, Np, A);
     VITSEG_LAUNCH_CHECK("attn_cls_f32");
     return VITSEG_OK;
 }

@@ -21,9 +21,9 @@ struct TrainPlan {
     LayerBufs lb;                 // offsets inside a layer block
     size_t xfinal, hf, f, z;      // after the last layer
     size_t dxa, dxb, dh, dqkv, du, dctx, dvec, g, dz, df, t, wd, scratch, wscratch, ce_partial, total;
-    // bf16 training only: bf16 copy of the fp32 residual gradient, transposed operands of the wgrad GEMMs
-    // ([rows][Kpad] with the token index contiguous), transposed weight for dgrad, zero page
-    size_t dxc, ta, tb, wt, zero, dhf, Kpad;
+    // bf16 training only: bf16 copy of the fp32 residual gradient, transposed weight for dgrad, zero page,
+    // fp32 gradient of the final LayerNorm output
+    size_t dxc, wt, zero, dhf, Kpad;
 };
 
 TrainPlan make_train_plan(const Shape& s, int B, int precision) {
@@ -91,8 +91,6 @@ TrainPlan make_train_plan(const Shape& s, int B, int precision) {
         const size_t wide = (size_t)(s.I > 3 * s.D ? s.I : 3 * s.D);
         p.dxc = take(p.Mt * s.D * 2);
         p.dhf = take(p.Mp * s.D * 4);
-        p.ta = take(wide * p.Kpad * 2);
-        p.tb = take((size_t)(s.I > s.D ? s.I : s.D) * p.Kpad * 2);
         p.wt = take(wide * s.D * 2);
         p.zero = take(256);
         size_t w = wgrad_bf16_scratch_floats(s.D, s.I, (int)p.Kpad);
@@ -157,8 +155,8 @@ GemmArgs lin(const void* A, const void* W, const float* bias, const float* R, vo
 
 // =========================================================================================================
 // Mixed-precision (bf16 operands, fp32 master weights / residual stream / gradients) training path.
-// All GEMMs are the N-form bf16 kernel: dgrad multiplies by a transposed bf16 copy of the weight, wgrad by
-// transposed copies of dY and X (token index contiguous, zero-padded to a multiple of 64), split-K, fp32 out.
+// dgrad = N-form bf16 GEMM against a transposed bf16 copy of the (small) weight; wgrad = the T-form/T-form
+// kernel (dY and X are read as they lie, MFMA operands gathered with transposed LDS reads), split-K, fp32 out.
 // The head (1.7 % of the FLOPs) and the patch embedding stay on the fp32 kernels.
 int forward_train_bf16(Ctx& c, const float* x, float* logits) {
     const Shape& s = c.s;
@@ -219,7 +217,7 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
     auto G = [&](int t, int l = 0) { return grads + tensor_offset(c.lay, t, l); };
     float* scratch = c.T(c.p.scratch);
     float* wscr = c.T(c.p.wscratch);
-    void *tA = c.TV(c.p.ta), *tB = c.TV(c.p.tb), *wT = c.TV(c.p.wt), *dXc = c.TV(c.p.dxc);
+    void *wT = c.TV(c.p.wt), *dXc = c.TV(c.p.dxc);
     {
         hipError_t e = hipMemsetAsync(grads, 0, c.lay.total * sizeof(float), st);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(grads)");
@@ -231,7 +229,7 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
         g.zeros = c.ws + c.p.zero;
         return launch_wgrad_bf16_tt(g, wscr, st);
     };
-    (void)tA; (void)tB; (void)Kpad;
+    (void)Kpad;
     // dX[Mt,Kd] = dY[Mt,Nd] . W[Nd,Kd]  with W^T materialised as [Kd][Nd] bf16
     auto dgrad = [&](const void* dY, const unsigned short* Wlp, void* dX, int Nd, int Kd, int epi, const void* R) {
         int r;
