@@ -127,7 +127,7 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"ViT-B/16 seg TRAINING step (forward + CE + backward + Adam), batch {B}/GPU x "
-                                   f"512x512, {args.precision}, dropout 0", "batch_per_gpu": B,
+                                   f"512x512, {args.precision}, dropout {model.dropout} (reference: 0.1)", "batch_per_gpu": B,
                        "global_batch": B * world,
                        "parallelism": f"data-parallel x{world}, flat-arena gradient all-reduce (RCCL)"},
             "whole_model": {"flops_per_image": flops_img,
@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.1, help="train mode: dropout probability (reference 0.1)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="train: one step = forward + CE + backward + gradient all-reduce + Adam (fp32)")
     args = ap.parse_args()
@@ -167,7 +168,8 @@ def main():
     B = args.batch
     model = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
                                  cfg.num_attention_heads, image_size=cfg.image_size,
-                                 precision={"f32": "fp32", "bf16": "bf16"}[args.precision], device=dev).eval()
+                                 precision={"f32": "fp32", "bf16": "bf16"}[args.precision], dropout=args.dropout,
+                                 device=dev).eval()
     sd_np = synth.make_state_dict(cfg, seed=1)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     images_np = synth.make_images(cfg, B, seed=0, first_image=rank * B)  # this rank's shard of the image stream

@@ -148,7 +148,11 @@ int vitseg_ce_loss(const float* lowres, const void* target, int target_is_u8, fl
                    float* loss, int batch, int C, int g, int S, void* stream);
 
 /* ---- training (replaces autograd behind LightningViTModel.training_step, classes.py:276-285, and
- *      torch.optim.Adam(lr=1e-5).step(), classes.py:296-297).  Dropout p = 0.  VITSEG_BF16 = mixed precision:
+ *      torch.optim.Adam(lr=1e-5).step(), classes.py:296-297).  dropout_p (the reference trains with 0.1,
+ *      classes.py:233-234) is applied at the four sites of HF ViT (embeddings, attention probabilities,
+ *      attention output, MLP output) with a counter-based generator: the mask is a pure function of
+ *      (dropout_seed, layer, site, element), so the SAME (p, seed) must be passed to vitseg_forward_train
+ *      and vitseg_backward of one step; torch's RNG stream cannot be matched.  VITSEG_BF16 = mixed precision:
  *      bf16 MFMA operands (params_bf16 shadow arena, bf16 saved activations), fp32 master parameters,
  *      residual stream, LayerNorm / softmax statistics and gradients.
  * vitseg_forward_train saves every activation the backward needs inside `workspace`
@@ -158,11 +162,12 @@ int vitseg_ce_loss(const float* lowres, const void* target, int target_is_u8, fl
  * arena-shaped fp32 buffer (same offsets as the parameters). */
 int vitseg_train_workspace(const vitseg_config* cfg, int batch, int precision, size_t* bytes);
 int vitseg_forward_train(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x,
-                         int batch, int precision, float* logits, void* workspace, size_t workspace_bytes,
-                         void* stream);
+                         int batch, int precision, float dropout_p, uint64_t dropout_seed, float* logits,
+                         void* workspace, size_t workspace_bytes, void* stream);
 int vitseg_backward(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x, int batch,
-                    int precision, const void* target, int target_is_u8, const float* grad_logits, float* grads,
-                    float* loss, void* workspace, size_t workspace_bytes, void* stream);
+                    int precision, float dropout_p, uint64_t dropout_seed, const void* target, int target_is_u8,
+                    const float* grad_logits, float* grads, float* loss, void* workspace, size_t workspace_bytes,
+                    void* stream);
 /* one Adam step over a flat fp32 buffer (torch.optim.Adam semantics, weight_decay 0, amsgrad off);
  * step is 1-based; gradients are multiplied by grad_scale first (1/world for summed all-reduce). */
 int vitseg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n_floats, float lr,

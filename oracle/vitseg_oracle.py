@@ -45,7 +45,7 @@ def patch_embed(x, w, b, P):
 
 
 # ----------------------------------------------------------------------------- a3
-def embeddings(x, sd, P):
+def embeddings(x, sd, P, drop=None):
     """cat(cls, patches) + position embeddings; eval mode (dropout off).
 
     transformers/models/vit/modeling_vit.py:129-161.
@@ -53,7 +53,10 @@ def embeddings(x, sd, P):
     t = patch_embed(x, sd["backbone.embeddings.patch_embeddings.projection.weight"],
                     sd["backbone.embeddings.patch_embeddings.projection.bias"], P)
     cls = sd["backbone.embeddings.cls_token"].expand(t.shape[0], -1, -1)
-    return torch.cat([cls, t], dim=1) + sd["backbone.embeddings.position_embeddings"]
+    t = torch.cat([cls, t], dim=1) + sd["backbone.embeddings.position_embeddings"]
+    if drop is not None:  # train mode: modeling_vit.py:159 `embeddings = self.dropout(embeddings)`
+        t = t * drop.rows(0, 0, t.shape).to(t.dtype)
+    return t
 
 
 # ----------------------------------------------------------------------------- a4
@@ -68,7 +71,7 @@ def layer_norm(x, w, b, eps=1e-12):
 
 
 # ----------------------------------------------------------------------------- a5/a6
-def attention(h, sd, prefix, A):
+def attention(h, sd, prefix, A, drop=None, layer=0):
     """q/k/v Linear, softmax(q k^T * hd^-0.5) v, o_proj.  No mask, eval mode.
 
     transformers/models/vit/modeling_vit.py:164-189 (eager core; the default sdpa
@@ -84,8 +87,12 @@ def attention(h, sd, prefix, A):
 
     q, k, v = proj("q_proj"), proj("k_proj"), proj("v_proj")
     s = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), dim=-1)
+    if drop is not None:  # modeling_vit.py:184 dropout on the attention probabilities
+        s = s * drop.attn(layer, s.shape).to(s.dtype)
     ctx = (s @ v).transpose(1, 2).reshape(B, N, D)
     out = ctx @ sd[prefix + "attention.o_proj.weight"].T + sd[prefix + "attention.o_proj.bias"]
+    if drop is not None:  # modeling_vit.py:276 hidden dropout after the attention output projection
+        out = out * drop.rows(layer, 2, out.shape).to(out.dtype)
     return q, k, v, ctx, out
 
 
@@ -95,34 +102,39 @@ def gelu_erf(u):
     return 0.5 * u * (1.0 + torch.erf(u / math.sqrt(2.0)))
 
 
-def mlp(h, sd, prefix):
-    """fc2(gelu(fc1(h))).  transformers/models/vit/modeling_vit.py:249-254."""
+def mlp(h, sd, prefix, drop=None, layer=0):
+    """fc2(gelu(fc1(h))).  transformers/models/vit/modeling_vit.py:249-254 (+ hidden dropout, :283)."""
     u = gelu_erf(h @ sd[prefix + "mlp.fc1.weight"].T + sd[prefix + "mlp.fc1.bias"])
-    return u @ sd[prefix + "mlp.fc2.weight"].T + sd[prefix + "mlp.fc2.bias"]
+    out = u @ sd[prefix + "mlp.fc2.weight"].T + sd[prefix + "mlp.fc2.bias"]
+    if drop is not None:
+        out = out * drop.rows(layer, 3, out.shape).to(out.dtype)
+    return out
 
 
 # ----------------------------------------------------------------------------- a8
-def encoder_layer(t, sd, i, A, eps=1e-12, stages=None):
+def encoder_layer(t, sd, i, A, eps=1e-12, stages=None, drop=None):
     """Pre-LN block.  transformers/models/vit/modeling_vit.py:266-286."""
     p = f"backbone.layers.{i}."
     h = layer_norm(t, sd[p + "layernorm_before.weight"], sd[p + "layernorm_before.bias"], eps)
-    q, k, v, ctx, a = attention(h, sd, p, A)
+    q, k, v, ctx, a = attention(h, sd, p, A, drop, i)
     t = t + a
     h2 = layer_norm(t, sd[p + "layernorm_after.weight"], sd[p + "layernorm_after.bias"], eps)
-    m = mlp(h2, sd, p)
+    m = mlp(h2, sd, p, drop, i)
     if stages is not None and i == 0:
         stages.update(ln1_0=h, q_0=q, k_0=k, v_0=v, ctx_0=ctx, attn_res_0=t, mlp_0=m)
     return t + m
 
 
 # ----------------------------------------------------------------------------- a9
-def encoder(x, sd, cfg, stages=None):
-    """ViTModel.forward minus the discarded pooler.  modeling_vit.py:356-388."""
-    t = embeddings(x, sd, cfg.patch_size)
+def encoder(x, sd, cfg, stages=None, drop=None):
+    """ViTModel.forward minus the discarded pooler.  modeling_vit.py:356-388.
+    `drop` (optional, train mode): an object with rows(layer, site, shape) / attn(layer, shape) returning the
+    multiplicative dropout masks (keep -> 1/(1-p), drop -> 0) so that a test can inject the build's masks."""
+    t = embeddings(x, sd, cfg.patch_size, drop)
     if stages is not None:
         stages["embeddings"] = t
     for i in range(cfg.num_hidden_layers):
-        t = encoder_layer(t, sd, i, cfg.num_attention_heads, cfg.layer_norm_eps, stages)
+        t = encoder_layer(t, sd, i, cfg.num_attention_heads, cfg.layer_norm_eps, stages, drop)
         if stages is not None:
             stages[f"layer_{i}"] = t
     t = layer_norm(t, sd["backbone.layernorm.weight"], sd["backbone.layernorm.bias"], cfg.layer_norm_eps)
@@ -193,7 +205,7 @@ def upsample_bilinear(z, size):
 
 
 # ----------------------------------------------------------------------------- a1..a12
-def forward(x, sd, cfg, stages=None):
+def forward(x, sd, cfg, stages=None, drop=None):
     """ViTSegmentationModel.forward, eval mode.  model/CE/classes.py:246-262.
 
     Raises like the reference: ValueError on channel / image-size mismatch
@@ -205,7 +217,7 @@ def forward(x, sd, cfg, stages=None):
     if x.shape[2] != cfg.image_size or x.shape[3] != cfg.image_size:
         raise ValueError(f"Input image size ({x.shape[2]}*{x.shape[3]}) doesn't match model "
                          f"({cfg.image_size}*{cfg.image_size}).")
-    hidden = encoder(x, sd, cfg, stages)
+    hidden = encoder(x, sd, cfg, stages, drop)
     z = seg_head(hidden, sd)
     if stages is not None:
         stages["lowres_logits"] = z

@@ -91,7 +91,7 @@ def test_attention_backward(B, Np, A):
 def _build(g: Golden):
     c = g.cfg
     lm = LightningViTModel(c.num_classes, c.patch_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
-                           image_size=c.image_size, device=DEV)
+                           image_size=c.image_size, dropout=0.0, device=DEV)  # parity runs with dropout off
     lm.load_state_dict({"model." + k: v for k, v in g.state_dict().items()})
     return lm
 
@@ -127,7 +127,7 @@ def test_logits_autograd_matches_oracle():
     wgt = _rand(2, 3, 96, 96, seed=6)
     leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
     (O.forward(x.double(), leaf, cfg) * wgt.double()).sum().backward()
-    m = ViTSegmentationModel(3, 16, 192, 2, 3, image_size=96, device=DEV).train()
+    m = ViTSegmentationModel(3, 16, 192, 2, 3, image_size=96, dropout=0.0, device=DEV).train()
     m.load_state_dict(sd)
     (m(x.to(DEV)) * wgt.to(DEV)).sum().backward()
     from visiontransformer_amd.params import arena_views
@@ -210,7 +210,7 @@ def test_paed_trainer_step_gradients_match_oracle():
     ref = (torch.nn.functional.binary_cross_entropy(preds, m) + 0.1 * paed.dice_loss(preds, m).double()
            + 5.0 * paed.paed_loss_soft(sdf_e.unsqueeze(1).double(), sdf_i.unsqueeze(1).double(), preds).abs())
     ref.backward()
-    t = paed.PAEDTrainer(1, 16, 192, 2, 3, image_size=96, device=DEV).train()
+    t = paed.PAEDTrainer(1, 16, 192, 2, 3, image_size=96, dropout=0.0, device=DEV).train()
     t.load_state_dict({"model." + k: v for k, v in sd.items()})
     loss = t.training_step((x.to(DEV), masks.to(DEV), sdf_e.to(DEV), sdf_i.to(DEV)), 0)
     loss.backward()
@@ -235,7 +235,7 @@ def test_bf16_training_step_close_to_reference(name):
     g = Golden(name)
     c = g.cfg
     lm = LightningViTModel(c.num_classes, c.patch_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
-                           image_size=c.image_size, precision="bf16", device=DEV).train()
+                           image_size=c.image_size, precision="bf16", dropout=0.0, device=DEV).train()
     lm.load_state_dict({"model." + k: v for k, v in g.state_dict().items()})
     loss = lm.training_step((g.images().to(DEV), g.targets().to(DEV)), 0)
     assert abs(float(loss.detach()) - float(g.z["train.loss"][0])) < 5e-3
@@ -258,3 +258,58 @@ def test_bf16_training_step_close_to_reference(name):
         worst = max(worst, rel)
         assert cos > 0.98 and rel < 0.2, (k, rel, cos)
     print(f"{name}: bf16 vs fp32 gradients, worst per-tensor relative L2 error {worst:.3e}")
+
+
+def _dropout_case():
+    cfg = ViTSegConfig(3, 16, 192, 2, 3, image_size=96)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=61).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 2, seed=8))
+    y = torch.from_numpy(synth.make_targets(cfg, 2, seed=8, size=96))
+    return cfg, sd, x, y
+
+
+def test_dropout_training_step_matches_oracle_with_identical_masks():
+    """Train-mode dropout (p = 0.1 at the four HF sites).  torch's RNG stream cannot be matched, but the build's
+    masks are a pure function of (seed, layer, site, element): tests/dropout_ref.py regenerates them in numpy and
+    injects them into the oracle, so forward AND backward can be compared exactly like the p = 0 case."""
+    from dropout_ref import Masks
+    from visiontransformer_amd.params import arena_views
+    cfg, sd, x, y = _dropout_case()
+    m = ViTSegmentationModel(3, 16, 192, 2, 3, image_size=96, dropout=0.1, device=DEV).train()
+    m.load_state_dict(sd)
+    seed64 = (m.dropout_seed * 0x9E3779B97F4A7C15 + 1 * 0x100000001B3 + 0) & (2 ** 64 - 1)  # first training forward
+    loss = m.ce_loss(x.to(DEV), y.to(DEV))
+    loss.backward()
+    masks = Masks(0.1, seed64, 2, cfg.num_patches, 3)
+    assert abs(float((masks.rows(0, 0, (2, 37, 192)) > 0).float().mean()) - 0.9) < 0.01
+    leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = O.ce_loss(O.forward(x.double(), leaf, cfg, drop=masks), y)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref)) < 2e-6
+    gv = arena_views(cfg, m.arena.grad)
+    for k, r in leaf.items():
+        err = (gv[k].cpu().double() - r.grad).abs().max().item()
+        assert err <= 3e-4 * max(r.grad.abs().max().item(), 1e-4), (k, err, r.grad.abs().max().item())
+    # a second step draws different masks; eval() / no_grad switch dropout off
+    l2 = float(m.ce_loss(x.to(DEV), y.to(DEV)).detach())
+    assert abs(l2 - float(loss.detach())) > 1e-7
+    m.eval()
+    with torch.no_grad():
+        l_eval = float(m.ce_loss(x.to(DEV), y.to(DEV)))
+    assert abs(l_eval - float(O.ce_loss(O.forward(x, sd, cfg), y))) < 2e-6
+
+
+def test_dropout_bf16_consistent_with_fp32_same_masks():
+    from visiontransformer_amd.params import arena_views
+    cfg, sd, x, y = _dropout_case()
+    grads = {}
+    for prec in ("fp32", "bf16"):
+        m = ViTSegmentationModel(3, 16, 192, 2, 3, image_size=96, dropout=0.1, precision=prec, device=DEV).train()
+        m.load_state_dict(sd)
+        m.ce_loss(x.to(DEV), y.to(DEV)).backward()  # same seed/step in both -> same masks
+        grads[prec] = arena_views(cfg, m.arena.grad.clone())
+    for k in grads["fp32"]:
+        a, b = grads["bf16"][k].double().flatten(), grads["fp32"][k].double().flatten()
+        if b.norm() < 1e-6:
+            continue
+        assert float((a - b).norm() / b.norm()) < 0.2 and float((a @ b) / (a.norm() * b.norm())) > 0.98, k

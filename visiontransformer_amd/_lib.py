@@ -78,8 +78,8 @@ def lib() -> C.CDLL:
         l.vitseg_ce_loss.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]
         f32 = C.c_float
         l.vitseg_train_workspace.argtypes = [pcfg, i32, i32, psz]
-        l.vitseg_forward_train.argtypes = [pcfg, vp, vp, vp, i32, i32, vp, vp, sz, vp]
-        l.vitseg_backward.argtypes = [pcfg, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+        l.vitseg_forward_train.argtypes = [pcfg, vp, vp, vp, i32, i32, f32, C.c_uint64, vp, vp, sz, vp]
+        l.vitseg_backward.argtypes = [pcfg, vp, vp, vp, i32, i32, f32, C.c_uint64, vp, i32, vp, vp, vp, vp, sz, vp]
         l.vitseg_adam_step.argtypes = [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, f32, vp]
         l.vitseg_op_gemm_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]

@@ -39,7 +39,8 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 
 
 template <bool RAGGED>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                           float* __restrict__ lse, int B, int Np, int A) {
+                                                           float* __restrict__ lse, int B, int Np, int A,
+                                                           DropArgs dr) {
     // [buffer][K|V][key * 64 + d] bf16, rows of 128 B with XOR-swizzled 16-B chunks: 32 KiB
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][KB * HD];
 
@@ -62,6 +63,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *(const f32x4*)(qbase + q_row * ld + 16 * s + 8 * lh);
 
+    // attention-probability dropout: the row sum keeps every term, only the P that multiplies V is masked
+    const unsigned dkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * (Np + 1) + q_local));
     // ---- online-softmax state initialised with the CLS key (raw-score units) ----
     float m_run, l_run;
     f32x16 o[2];
@@ -89,6 +92,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
                 o[dt][4 * g4 + 2] = bf_lo(t.y);
                 o[dt][4 * g4 + 3] = bf_hi(t.y);
             }
+        if (dr.thresh) {
+            const float kc = drop_keep(dkey, (unsigned)Np, dr.thresh) ? dr.scale : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= kc;
+        }
     }
 
     // ---- K/V staging: thread owns 16-B chunk lc (8 bf16) of keys lr + 32 i ----
@@ -175,9 +185,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, -mc));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c, -mc));
+                float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, -mc));
+                float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c, -mc));
                 psum += p0 + p1;
+                if (dr.thresh) {
+                    const unsigned k0 = (unsigned)(kt * KB + kb * 32);
+                    p0 = drop_keep(dkey, k0 + kappa(r, lh), dr.thresh) ? p0 * dr.scale : 0.f;
+                    p1 = drop_keep(dkey, k0 + kappa(r + 1, lh), dr.thresh) ? p1 * dr.scale : 0.f;
+                }
                 pk[kb][r >> 1] = pack_bf16(p0, p1);
             }
         l_run += psum;
@@ -228,7 +243,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 
 // The B*A CLS queries: one block per (head, image); plain VALU in fp32 on bf16 inputs.
 __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                            float* __restrict__ lse, int B, int Np, int A) {
+                                                            float* __restrict__ lse, int B, int Np, int A,
+                                                            DropArgs dr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int N = Np + 1;
     float* sc = sm;
@@ -303,6 +319,9 @@ __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __res
             const size_t row = key < Np ? row0 + key : cls_row;
             vu[u] = *(const uint2*)(vbase + row * ld + 4 * sub);
             pv[u] = key0 + 64 * u < N ? sc[key] : 0.f;
+            if (dr.thresh)
+                pv[u] = drop_keep(drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + Np)), (unsigned)key,
+                                  dr.thresh) ? pv[u] * dr.scale : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -323,20 +342,20 @@ __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __res
 
 }  // namespace
 
-int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, hipStream_t s) {
+int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_bf16: bad arguments");
     const dim3 grid((Np + QB - 1) / QB, A, B);
     if (Np % QB == 0)
         hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B, Np,
-                           A);
+                           A, dr);
     else
         hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B, Np,
-                           A);
+                           A, dr);
     VITSEG_LAUNCH_CHECK("attn_bf16");
     const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 64 * 64) * sizeof(float);
     VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_bf16: sequence too long for the CLS kernel");
     hipLaunchKernelGGL(attn_cls_bf16_kernel, dim3(A, B), dim3(1024), smem, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B,
-                       Np, A);
+                       Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_cls_bf16");
     return VITSEG_OK;
 }

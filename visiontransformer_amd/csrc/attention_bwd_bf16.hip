@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
                                                                   const bf16_t* __restrict__ dctx,
                                                                   const float* __restrict__ lse,
                                                                   const float* __restrict__ delta,
-                                                                  bf16_t* __restrict__ dqkv, int B, int Np, int A) {
+                                                                  bf16_t* __restrict__ dqkv, int B, int Np, int A,
+                                                                  DropArgs dr) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][TT * HD];  // [buffer][K|V]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
     }
     const size_t stat = ((size_t)b * A + head) * N + (q_valid ? nq : 0);
     const float lse_q = lse[stat], delta_q = delta[stat];
+    const unsigned dkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + nq));  // same mask as forward
 
     f32x16 dq[2];
 #pragma unroll
@@ -137,10 +139,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float d0 = 0.f, d1 = 0.f;
-                if (kt * TT + kb * 32 + kappa(r, lh) < N)
-                    d0 = __builtin_amdgcn_exp2f(fmaf(st[r], c, -lse_q)) * (dp[r] - delta_q);
-                if (kt * TT + kb * 32 + kappa(r + 1, lh) < N)
-                    d1 = __builtin_amdgcn_exp2f(fmaf(st[r + 1], c, -lse_q)) * (dp[r + 1] - delta_q);
+                const int k0 = kt * TT + kb * 32 + kappa(r, lh), k1 = kt * TT + kb * 32 + kappa(r + 1, lh);
+                float g0 = dp[r], g1 = dp[r + 1];
+                if (dr.thresh) {
+                    g0 = drop_keep(dkey, (unsigned)k0, dr.thresh) ? g0 * dr.scale : 0.f;
+                    g1 = drop_keep(dkey, (unsigned)k1, dr.thresh) ? g1 * dr.scale : 0.f;
+                }
+                if (k0 < N) d0 = __builtin_amdgcn_exp2f(fmaf(st[r], c, -lse_q)) * (g0 - delta_q);
+                if (k1 < N) d1 = __builtin_amdgcn_exp2f(fmaf(st[r + 1], c, -lse_q)) * (g1 - delta_q);
                 pk[r >> 1] = pack2_bf16(d0, d1);
             }
 #pragma unroll
@@ -174,7 +180,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                                                                    const bf16_t* __restrict__ dctx,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ delta,
-                                                                   bf16_t* __restrict__ dqkv, int B, int Np, int A) {
+                                                                   bf16_t* __restrict__ dqkv, int B, int Np, int A,
+                                                                   DropArgs dr) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][TT * HD];  // [buffer][Q|dO]
     __shared__ float stats[2][2][TT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -259,8 +266,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                 const int q0 = qb * 32 + kappa(r, lh), q1 = qb * 32 + kappa(r + 1, lh);
                 if (qt * TT + q0 < N) p0 = __builtin_amdgcn_exp2f(fmaf(st[r], c, -stats[buf][0][q0]));
                 if (qt * TT + q1 < N) p1 = __builtin_amdgcn_exp2f(fmaf(st[r + 1], c, -stats[buf][0][q1]));
-                pp[r >> 1] = pack2_bf16(p0, p1);
-                pd[r >> 1] = pack2_bf16(p0 * (dp[r] - stats[buf][1][q0]), p1 * (dp[r + 1] - stats[buf][1][q1]));
+                float k0 = 1.f, k1 = 1.f;
+                if (dr.thresh) {
+                    const unsigned base = (unsigned)((b * A + head) * N + qt * TT);
+                    k0 = drop_keep(drop_key(dr.seed, dr.stream, base + q0), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                    k1 = drop_keep(drop_key(dr.seed, dr.stream, base + q1), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                }
+                pp[r >> 1] = pack2_bf16(p0 * k0, p1 * k1);  // dropped P (what multiplied V in the forward)
+                pd[r >> 1] = pack2_bf16(p0 * (dp[r] * k0 - stats[buf][1][q0]), p1 * (dp[r + 1] * k1 - stats[buf][1][q1]));
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
 }  // namespace
 
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dvec,
-                              void* dqkv, int B, int Np, int A, hipStream_t s) {
+                              void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && dctx && lse && dvec && dqkv, VITSEG_EINVAL, "attention_bwd_bf16: null pointer");
     const int N = Np + 1;
     const size_t items = (size_t)B * A * N;
@@ -308,10 +321,10 @@ int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx
     VITSEG_LAUNCH_CHECK("attn_delta_bf16");
     const dim3 grid((N + TB - 1) / TB, A, B);
     hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec,
-                       (bf16_t*)dqkv, B, Np, A);
+                       (bf16_t*)dqkv, B, Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_bwd_dq_bf16");
     hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec,
-                       (bf16_t*)dqkv, B, Np, A);
+                       (bf16_t*)dqkv, B, Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_bwd_dkv_bf16");
     return VITSEG_OK;
 }

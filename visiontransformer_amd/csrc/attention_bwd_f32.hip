@@ -48,7 +48,7 @@ struct Stage {
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ delta, float* __restrict__ dqkv,
-                                                             int B, int Np, int A) {
+                                                             int B, int Np, int A, DropArgs dr) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][TT * HD];  // [buffer][K|V]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
     }
     const size_t stat = ((size_t)b * A + head) * N + (q_valid ? nq : 0);
     const float lse_q = lse[stat], delta_q = delta[stat];
+    const unsigned dkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + nq));  // same mask as forward
 
     f32x16 dq[2];
 #pragma unroll
@@ -135,7 +136,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
             for (int r = 0; r < 16; ++r) {
                 const bool kvalid = kt * TT + kb * 32 + kappa(r, lh) < N;
                 const float pv = kvalid ? __builtin_amdgcn_exp2f(st[r] - lse_q) : 0.f;
-                st[r] = pv * (dp[r] - delta_q);
+                float dpr = dp[r];
+                if (dr.thresh)
+                    dpr = drop_keep(dkey, (unsigned)(kt * TT + kb * 32 + kappa(r, lh)), dr.thresh) ? dpr * dr.scale : 0.f;
+                st[r] = pv * (dpr - delta_q);
             }
             // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
 #pragma unroll
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
                                                               const float* __restrict__ dctx,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta, float* __restrict__ dqkv,
-                                                              int B, int Np, int A) {
+                                                              int B, int Np, int A, DropArgs dr) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][TT * HD];  // [buffer][Q|dO]
     __shared__ float stats[2][2][TT];                                  // [buffer][lse|delta]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -265,8 +269,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
                 const int qq = qb * 32 + kappa(r, lh);
                 const bool qvalid = qt * TT + qq < N;
                 const float pv = qvalid ? __builtin_amdgcn_exp2f(st[r] - stats[buf][0][qq]) : 0.f;
-                st[r] = pv;                                   // P
-                dp[r] = pv * (dp[r] - stats[buf][1][qq]);     // dS
+                float keep = 1.f;
+                if (dr.thresh)
+                    keep = drop_keep(drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + qt * TT + qq)),
+                                     (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                st[r] = pv * keep;                                   // dropped P (what multiplied V in the forward)
+                dp[r] = pv * (dp[r] * keep - stats[buf][1][qq]);     // dS
             }
             // dV^T[d][key] += dO^T[d][query] P[query][key];  dK^T[d][key] += Q^T[d][query] dS[query][key]
 #pragma unroll
@@ -306,16 +314,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
 }  // namespace
 
 int launch_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dvec,
-                             float* dqkv, int B, int Np, int A, hipStream_t s) {
+                             float* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && dctx && lse && dvec && dqkv, VITSEG_EINVAL, "attention_bwd: null pointer");
     const int N = Np + 1;
     const size_t items = (size_t)B * A * N;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, ctx, dctx, dvec, B, Np, A);
     VITSEG_LAUNCH_CHECK("attn_delta");
     const dim3 grid((N + TB - 1) / TB, A, B);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_bwd_dq");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_bwd_dkv");
     return VITSEG_OK;
 }

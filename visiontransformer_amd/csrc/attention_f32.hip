@@ -34,7 +34,8 @@ __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 
 
 template <bool RAGGED>
 __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
-                                                          float* __restrict__ lse, int B, int Np, int A) {
+                                                          float* __restrict__ lse, int B, int Np, int A,
+                                                          DropArgs dr) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][KB * HD];  // [buffer][K|V][key*64 + d], 64 KiB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,6 +61,9 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
         for (int e = 0; e < 4; ++e) qreg[4 * c + e] = t[e] * qscale;
     }
 
+    // attention-probability dropout (modeling_vit.py:184): P is dropped AFTER normalisation, so the row sum l
+    // keeps every term and only the P that multiplies V is masked / rescaled
+    const unsigned dkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * (Np + 1) + q_local));
     // ---- online-softmax state, initialised with the CLS key ----
     float m_run, l_run;
     f32x16 o[2];
@@ -81,6 +85,13 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[dt][4 * g4 + e] = t[e];
             }
+        if (dr.thresh) {
+            const float kc = drop_keep(dkey, (unsigned)Np, dr.thresh) ? dr.scale : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= kc;
+        }
     }
 
     // ---- K/V tile staging: thread owns 16-B chunk lc of keys lr + 16 i ----
@@ -158,6 +169,14 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
                 psum += pv;
             }
         l_run = l_run * alpha + psum;
+        if (dr.thresh) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st[kb][r] = drop_keep(dkey, (unsigned)(kt * KB + kb * 32 + kappa(r, lh)), dr.thresh)
+                                    ? st[kb][r] * dr.scale : 0.f;
+        }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -201,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
 
 // The B*A CLS queries: one block per (head, image); plain VALU (1 x N x 64 per block).
 __global__ __launch_bounds__(1024) void attn_cls_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
-                                                           float* __restrict__ lse, int B, int Np, int A) {
+                                                           float* __restrict__ lse, int B, int Np, int A,
+                                                           DropArgs dr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // scores[N] then reduce scratch
     const int N = Np + 1;
     float* sc = sm;
@@ -277,6 +297,9 @@ __global__ __launch_bounds__(1024) void attn_cls_f32_kernel(const float* __restr
             const size_t row = key < Np ? row0 + key : cls_row;
             v4[u] = *(const f32x4*)(vbase + row * ld + 4 * sub);
             pv[u] = key0 + 64 * u < N ? sc[key] : 0.f;
+            if (dr.thresh)
+                pv[u] = drop_keep(drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + Np)), (unsigned)key,
+                                  dr.thresh) ? pv[u] * dr.scale : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -293,17 +316,17 @@ __global__ __launch_bounds__(1024) void attn_cls_f32_kernel(const float* __restr
 
 }  // namespace
 
-int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, hipStream_t s) {
+int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_f32: bad arguments");
     const dim3 grid((Np + QB - 1) / QB, A, B);
     if (Np % QB == 0)
-        hipLaunchKernelGGL(attn_f32_kernel<false>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A);
+        hipLaunchKernelGGL(attn_f32_kernel<false>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr);
     else
-        hipLaunchKernelGGL(attn_f32_kernel<true>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A);
+        hipLaunchKernelGGL(attn_f32_kernel<true>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_f32");
     const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 64 * 64) * sizeof(float);
     VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_f32: sequence too long for the CLS kernel");
-    hipLaunchKernelGGL(attn_cls_f32_kernel, dim3(A, B), dim3(1024), smem, s, qkv, ctx, lse, B, Np, A);
+    hipLaunchKernelGGL(attn_cls_f32_kernel, dim3(A, B), dim3(1024), smem, s, qkv, ctx, lse, B, Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_cls_f32");
     return VITSEG_OK;
 }

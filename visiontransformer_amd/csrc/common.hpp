@@ -41,6 +41,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// ---- dropout: counter-based keep/drop decision (no state, identical in forward and backward) ----
+// keep(seed, stream, major, minor) = fmix32(minor ^ fmix32(seed ^ stream*C1 ^ major*C2)) >= thresh, thresh = p * 2^32.
+// `stream` = layer * 8 + site (0 embeddings, 1 attention probabilities, 2 attention output, 3 MLP output);
+// (major, minor) = (row, column) of the tensor, or (bh * N + query, key) for attention probabilities.
+// The same function is restated in numpy by the tests (tests/dropout_ref.py) to inject identical masks
+// into the oracle.
+__host__ __device__ __forceinline__ unsigned fmix32(unsigned h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ unsigned drop_key(unsigned seed, unsigned stream, unsigned major) {
+    return fmix32(seed ^ (stream * 0x9E3779B1u) ^ (major * 0x85EBCA77u));
+}
+__host__ __device__ __forceinline__ bool drop_keep(unsigned key, unsigned minor, unsigned thresh) {
+    return fmix32(minor ^ key) >= thresh;
+}
+struct DropArgs {
+    unsigned thresh;  // 0 = dropout off
+    unsigned seed;
+    unsigned stream;
+    float scale;      // 1 / (1 - p)
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -402,6 +402,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                     if (EPI == EPI_GELU && p.aux) aux4[e] = x;
                     if (EPI == EPI_GELU) x = (sizeof(T) == 4) ? gelu_erf(x) : gelu_erf_fast(x);
                     if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
+                    if (EPI == EPI_RESADD && p.drop.thresh)
+                        x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow), gcol + e, p.drop.thresh)
+                                ? x * p.drop.scale : 0.f;
                     if (EPI == EPI_RESADD || EPI == EPI_POS) x = extra[ps][e] + x;
                     if (EPI == EPI_DGELU) x *= gelu_erf_grad(extra[ps][e]);
                     v[ps][e] = x;
@@ -734,6 +737,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
                     float x = v[ps][e] + bias4[e];
                     if (EPI == EPI_GELU) x = gelu_erf_fast(x);
                     if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
+                    if (EPI == EPI_RESADD && p.drop.thresh)
+                        x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow), gcol + e, p.drop.thresh)
+                                ? x * p.drop.scale : 0.f;
                     if (EPI == EPI_RESADD) x = extra[ps][e] + x;
                     v[ps][e] = x;
                 }

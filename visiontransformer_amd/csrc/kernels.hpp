@@ -36,6 +36,7 @@ struct GemmArgs {
     const void* zeros;  // >= 128 zero bytes (bf16 A_CONV3: source of the padding taps)
     int splitk;           // > 1: grid.y slices of the K range, each writing C + y * split_stride
     size_t split_stride;
+    DropArgs drop;        // EPI_RESADD: C = R + dropout(acc + bias)   (hidden dropout, modeling_vit.py:276,283)
 };
 
 int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s);
@@ -53,13 +54,13 @@ int launch_layernorm(const float* x, const float* w, const float* b, void* y, in
 
 // Multi-head self-attention core (a6) on the patches-first row layout.
 // lse (optional): fp32 [B, A, Np+1] log2-domain log-sum-exp per query (CLS last), saved for the backward
-int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, hipStream_t s);
+int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s);
 // dqkv[Mt,3D] from dctx[Mt,D]; dvec: scratch fp32 [B, A, Np+1]
 int launch_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dvec,
-                             float* dqkv, int B, int Np, int A, hipStream_t s);
-int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, hipStream_t s);
+                             float* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s);
+int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s);
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dvec,
-                              void* dqkv, int B, int Np, int A, hipStream_t s);
+                              void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s);
 
 // seg_head.2 (1x1 conv) on the ReLU'd mid features -> NCHW low-res logits (a11)
 int launch_head1x1(const float* F, const float* W2, const float* b2, float* Z, int B, int Np, int C, hipStream_t s);
@@ -75,6 +76,9 @@ int launch_ce_loss(const float* Z, const void* target, int target_is_u8, float* 
 int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int Np, int D, hipStream_t s);
 
 int launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+// dropout on a row-major [rows][cols] fp32 tensor: dst = keep ? src * scale : 0 (dst may alias src; dst_bf16 selects
+// a bf16 destination).  Used for the embedding dropout and for masking branch gradients in the backward.
+int launch_dropout_rows(const float* src, void* dst, int dst_bf16, int rows, int cols, DropArgs d, hipStream_t s);
 
 // ---- backward pass (backward.hip) ----
 size_t colsum_scratch_floats(int M, int N);

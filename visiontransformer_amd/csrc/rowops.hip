@@ -88,7 +88,41 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, unsigned short* 
     }
 }
 
+template <typename OutT>
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restrict__ src, OutT* __restrict__ dst,
+                                                           int rows, int cols4, DropArgs d) {
+    const size_t total = (size_t)rows * cols4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const unsigned row = (unsigned)(i / cols4), c0 = (unsigned)(i % cols4) * 4;
+        const unsigned key = drop_key(d.seed, d.stream, row);
+        f32x4 v = ((const f32x4*)src)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = drop_keep(key, c0 + e, d.thresh) ? v[e] * d.scale : 0.f;
+        if constexpr (sizeof(OutT) == 4) {
+            ((f32x4*)dst)[i] = v;
+        } else {
+            uint2 h;
+            h.x = pack2_bf16(v[0], v[1]);
+            h.y = pack2_bf16(v[2], v[3]);
+            ((uint2*)dst)[i] = h;
+        }
+    }
+}
+
 }  // namespace
+
+int launch_dropout_rows(const float* src, void* dst, int dst_bf16, int rows, int cols, DropArgs d, hipStream_t s) {
+    VITSEG_CHECK_ARG(cols % 4 == 0, VITSEG_EINVAL, "dropout_rows: cols %% 4");
+    const size_t n4 = (size_t)rows * (cols / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    if (dst_bf16)
+        hipLaunchKernelGGL(dropout_rows_kernel<unsigned short>, dim3(blocks), dim3(256), 0, s, src, (unsigned short*)dst,
+                           rows, cols / 4, d);
+    else
+        hipLaunchKernelGGL(dropout_rows_kernel<float>, dim3(blocks), dim3(256), 0, s, src, (float*)dst, rows, cols / 4, d);
+    VITSEG_LAUNCH_CHECK("dropout_rows");
+    return VITSEG_OK;
+}
 
 int launch_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int D, float eps,
                      bool out_bf16, hipStream_t s) {

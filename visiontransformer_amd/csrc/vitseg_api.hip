@@ -230,8 +230,8 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         if ((rc = gemm(g, EPI_BIAS, VITSEG_K_GEMM_BIAS))) return rc;
         {
             ProfScope ps(VITSEG_K_ATTENTION, 4.0 * batch * s.A * (double)s.N * s.N * 64, st);
-            rc = lp ? launch_attention_bf16(QKV, H, nullptr, batch, s.Np, s.A, st)
-                    : launch_attention_f32((const float*)QKV, (float*)H, nullptr, batch, s.Np, s.A, st);
+            rc = lp ? launch_attention_bf16(QKV, H, nullptr, batch, s.Np, s.A, DropArgs{}, st)
+                    : launch_attention_f32((const float*)QKV, (float*)H, nullptr, batch, s.Np, s.A, DropArgs{}, st);
             if (rc) return rc;
         }
         g = GemmArgs{};
@@ -354,8 +354,8 @@ int vitseg_op_gemm_f32(const float* A, const float* Wt, const float* R, float* C
 int vitseg_op_attention_bwd_f32(const float* qkv, const float* dctx, float* ctx_out, float* lse_out, float* scratch,
                                 float* dqkv, int batch, int num_patches, int num_heads, void* stream) {
     VITSEG_CHECK_ARG(qkv && dctx && ctx_out && lse_out && scratch && dqkv, VITSEG_EINVAL, "attention_bwd: null pointer");
-    if (int rc = launch_attention_f32(qkv, ctx_out, lse_out, batch, num_patches, num_heads, (hipStream_t)stream)) return rc;
-    return launch_attention_bwd_f32(qkv, ctx_out, dctx, lse_out, scratch, dqkv, batch, num_patches, num_heads,
+    if (int rc = launch_attention_f32(qkv, ctx_out, lse_out, batch, num_patches, num_heads, DropArgs{}, (hipStream_t)stream)) return rc;
+    return launch_attention_bwd_f32(qkv, ctx_out, dctx, lse_out, scratch, dqkv, batch, num_patches, num_heads, DropArgs{},
                                     (hipStream_t)stream);
 }
 
@@ -365,11 +365,11 @@ int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, 
 }
 
 int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream) {
-    return launch_attention_bf16(qkv, ctx, nullptr, batch, num_patches, num_heads, (hipStream_t)stream);
+    return launch_attention_bf16(qkv, ctx, nullptr, batch, num_patches, num_heads, DropArgs{}, (hipStream_t)stream);
 }
 
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
-    return launch_attention_f32(qkv, ctx, nullptr, batch, num_patches, num_heads, (hipStream_t)stream);
+    return launch_attention_f32(qkv, ctx, nullptr, batch, num_patches, num_heads, DropArgs{}, (hipStream_t)stream);
 }
 
 int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask, int batch, int C, int g, int S,

@@ -24,6 +24,7 @@ struct TrainPlan {
     // bf16 training only: bf16 copy of the fp32 residual gradient, transposed weight for dgrad, zero page,
     // fp32 gradient of the final LayerNorm output
     size_t dxc, wt, zero, dhf, Kpad;
+    size_t dxm;  // fp32 path with dropout: masked copy of the residual gradient that enters a dropped branch
 };
 
 TrainPlan make_train_plan(const Shape& s, int B, int precision) {
@@ -86,6 +87,7 @@ TrainPlan make_train_plan(const Shape& s, int B, int precision) {
         p.wscratch = take(w * 4);
     }
     p.ce_partial = take(ce_partial_count(B, s.S) * 8);
+    p.dxm = take(MtD);
     if (lp) {
         p.Kpad = up(p.Mt, 64);
         const size_t wide = (size_t)(s.I > 3 * s.D ? s.I : 3 * s.D);
@@ -116,6 +118,19 @@ struct Ctx {
     int B;
     float eps;
     bool lp;
+    float drop_p = 0.f;
+    unsigned drop_seed = 0;
+    // dropout sites: 0 embeddings, 1 attention probabilities, 2 attention output, 3 MLP output (modeling_vit.py:159,184,276,283)
+    DropArgs dr(int layer, int site) const {
+        DropArgs d{};
+        if (drop_p > 0.f) {
+            d.thresh = (unsigned)((double)drop_p * 4294967296.0);
+            d.seed = drop_seed;
+            d.stream = (unsigned)(layer * 8 + site);
+            d.scale = 1.0f / (1.0f - drop_p);
+        }
+        return d;
+    }
     const unsigned short* params_lp;
     const unsigned short* WL(int t, int l = 0) const { return params_lp + tensor_offset(lay, t, l); }
     void* LV(int l, size_t off) const { return (void*)(ws + p.layer0 + (size_t)l * p.layer_stride + off); }
@@ -169,6 +184,7 @@ int forward_train_bf16(Ctx& c, const float* x, float* logits) {
         g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
         if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st))) return rc;
         if ((rc = launch_cls_rows(c.W(VITSEG_T_CLS), c.W(VITSEG_T_POS), X0, batch, s.Np, D, st))) return rc;
+        if (c.drop_p > 0.f && (rc = launch_dropout_rows(X0, X0, 0, Mt, D, c.dr(0, 0), st))) return rc;
     }
     for (int l = 0; l < s.L; ++l) {
         float* Xin = c.L(l, c.p.lb.xin);
@@ -179,8 +195,9 @@ int forward_train_bf16(Ctx& c, const float* x, float* logits) {
             return rc;
         GemmArgs g = lin(H1, c.WL(VITSEG_T_WQKV, l), c.W(VITSEG_T_BQKV, l), nullptr, QKV, Mt, 3 * D, D, D, 3 * D);
         if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_BIAS, st))) return rc;
-        if ((rc = launch_attention_bf16(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, st))) return rc;
+        if ((rc = launch_attention_bf16(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, c.dr(l, 1), st))) return rc;
         g = lin(CTX, c.WL(VITSEG_T_WO, l), c.W(VITSEG_T_BO, l), Xin, Xmid, Mt, D, D, D, D);
+        g.drop = c.dr(l, 2);
         if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_RESADD, st))) return rc;
         if ((rc = launch_layernorm(Xmid, c.W(VITSEG_T_LN2_W, l), c.W(VITSEG_T_LN2_B, l), H2, Mt, D, c.eps, true, st)))
             return rc;
@@ -188,6 +205,7 @@ int forward_train_bf16(Ctx& c, const float* x, float* logits) {
         g.aux = c.LV(l, c.p.lb.upre);
         if ((rc = launch_gemm_bf16_train(g, EPI_GELU, 0, nullptr, st))) return rc;
         g = lin(c.LV(l, c.p.lb.uact), c.WL(VITSEG_T_W2, l), c.W(VITSEG_T_B2, l), Xmid, Xout, Mt, D, I, I, D);
+        g.drop = c.dr(l, 3);
         if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_RESADD, st))) return rc;
     }
     void* Hf = c.TV(c.p.hf);
@@ -280,8 +298,13 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
     // ---- 4. encoder layers ----
     void *dH = c.TV(c.p.dh), *dU = c.TV(c.p.du), *dQKV = c.TV(c.p.dqkv), *dCTX = c.TV(c.p.dctx);
     for (int l = s.L - 1; l >= 0; --l) {
-        if ((rc = launch_cast_bf16(dXa, dXc, (size_t)Mt * D, st))) return rc;
-        if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
+        if (c.drop_p > 0.f) {  // gradient entering the dropped branch: mask fused into the bf16 cast
+            if ((rc = launch_dropout_rows(dXa, dXc, 1, Mt, D, c.dr(l, 3), st))) return rc;
+            if ((rc = launch_colsum(dXc, 1, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
+        } else {
+            if ((rc = launch_cast_bf16(dXa, dXc, (size_t)Mt * D, st))) return rc;
+            if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
+        }
         if ((rc = wgrad(dXc, c.LV(l, c.p.lb.uact), G(VITSEG_T_W2, l), D, I))) return rc;
         if ((rc = dgrad(dXc, c.WL(VITSEG_T_W2, l), dU, D, I, EPI_DGELU, c.LV(l, c.p.lb.upre)))) return rc;
         if ((rc = launch_colsum(dU, 1, G(VITSEG_T_B1, l), scratch, Mt, I, I, st))) return rc;
@@ -290,12 +313,17 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
         if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xmid), c.W(VITSEG_T_LN2_W, l), dH, 1, dXa, dXb, G(VITSEG_T_LN2_W, l),
                                        G(VITSEG_T_LN2_B, l), scratch, Mt, D, c.eps, st)))
             return rc;
-        if ((rc = launch_cast_bf16(dXb, dXc, (size_t)Mt * D, st))) return rc;
-        if ((rc = launch_colsum(dXb, 0, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
+        if (c.drop_p > 0.f) {
+            if ((rc = launch_dropout_rows(dXb, dXc, 1, Mt, D, c.dr(l, 2), st))) return rc;
+            if ((rc = launch_colsum(dXc, 1, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
+        } else {
+            if ((rc = launch_cast_bf16(dXb, dXc, (size_t)Mt * D, st))) return rc;
+            if ((rc = launch_colsum(dXb, 0, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
+        }
         if ((rc = wgrad(dXc, c.LV(l, c.p.lb.ctx), G(VITSEG_T_WO, l), D, D))) return rc;
         if ((rc = dgrad(dXc, c.WL(VITSEG_T_WO, l), dCTX, D, D, EPI_BIAS, nullptr))) return rc;
         if ((rc = launch_attention_bwd_bf16(c.LV(l, c.p.lb.qkv), c.LV(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
-                                            c.T(c.p.dvec), dQKV, B, s.Np, s.A, st)))
+                                            c.T(c.p.dvec), dQKV, B, s.Np, s.A, c.dr(l, 1), st)))
             return rc;
         if ((rc = launch_colsum(dQKV, 1, G(VITSEG_T_BQKV, l), scratch, Mt, 3 * D, 3 * D, st))) return rc;
         if ((rc = wgrad(dQKV, c.LV(l, c.p.lb.h1), G(VITSEG_T_WQKV, l), 3 * D, D))) return rc;
@@ -305,6 +333,7 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
             return rc;
     }
     // ---- 5. embeddings (fp32) ----
+    if (c.drop_p > 0.f && (rc = launch_dropout_rows(dXa, dXa, 0, Mt, D, c.dr(0, 0), st))) return rc;
     if ((rc = launch_embed_bwd(dXa, G(VITSEG_T_POS), G(VITSEG_T_CLS), B, s.Np, D, st))) return rc;
     if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_PATCH_B), scratch, Mp, D, D, st))) return rc;
     if ((rc = launch_im2col_patch(x, c.T(c.p.t), B, s.Cin, s.S, s.P, st))) return rc;
@@ -327,10 +356,13 @@ int vitseg_train_workspace(const vitseg_config* cfg, int batch, int precision, s
 }
 
 int vitseg_forward_train(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x,
-                         int batch, int precision, float* logits, void* workspace, size_t workspace_bytes,
-                         void* stream) {
+                         int batch, int precision, float dropout_p, uint64_t dropout_seed, float* logits,
+                         void* workspace, size_t workspace_bytes, void* stream) {
     Ctx c;
     if (int rc = init_ctx(c, cfg, params, batch, precision, workspace, workspace_bytes, stream)) return rc;
+    VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "dropout_p %f", dropout_p);
+    c.drop_p = dropout_p;
+    c.drop_seed = (unsigned)(dropout_seed ^ (dropout_seed >> 32));
     VITSEG_CHECK_ARG(x, VITSEG_EINVAL, "x is null");
     VITSEG_CHECK_ARG(!c.lp || params_bf16, VITSEG_EINVAL, "bf16 training needs the bf16 arena");
     c.params_lp = (const unsigned short*)params_bf16;
@@ -346,6 +378,7 @@ int vitseg_forward_train(const vitseg_config* cfg, const float* params, const vo
         g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
         if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st))) return rc;
         if ((rc = launch_cls_rows(c.W(VITSEG_T_CLS), c.W(VITSEG_T_POS), X0, batch, s.Np, D, st))) return rc;
+        if (c.drop_p > 0.f && (rc = launch_dropout_rows(X0, X0, 0, Mt, D, c.dr(0, 0), st))) return rc;
     }
     for (int l = 0; l < s.L; ++l) {
         float* Xin = c.L(l, c.p.lb.xin);
@@ -359,8 +392,9 @@ int vitseg_forward_train(const vitseg_config* cfg, const float* params, const vo
             return rc;
         GemmArgs g = lin(H1, c.W(VITSEG_T_WQKV, l), c.W(VITSEG_T_BQKV, l), nullptr, QKV, Mt, 3 * D, D, D, 3 * D);
         if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_BIAS, st))) return rc;
-        if ((rc = launch_attention_f32(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, st))) return rc;
+        if ((rc = launch_attention_f32(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, c.dr(l, 1), st))) return rc;
         g = lin(CTX, c.W(VITSEG_T_WO, l), c.W(VITSEG_T_BO, l), Xin, Xmid, Mt, D, D, D, D);
+        g.drop = c.dr(l, 2);
         if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_RESADD, st))) return rc;
         if ((rc = launch_layernorm(Xmid, c.W(VITSEG_T_LN2_W, l), c.W(VITSEG_T_LN2_B, l), H2, Mt, D, c.eps, false, st)))
             return rc;
@@ -368,6 +402,7 @@ int vitseg_forward_train(const vitseg_config* cfg, const float* params, const vo
         g.aux = c.L(l, c.p.lb.upre);
         if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_GELU, st))) return rc;
         g = lin(c.L(l, c.p.lb.uact), c.W(VITSEG_T_W2, l), c.W(VITSEG_T_B2, l), Xmid, Xout, Mt, D, I, I, D);
+        g.drop = c.dr(l, 3);
         if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_RESADD, st))) return rc;
     }
     float* Hf = c.T(c.p.hf);
@@ -386,10 +421,14 @@ int vitseg_forward_train(const vitseg_config* cfg, const float* params, const vo
 }
 
 int vitseg_backward(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x, int batch,
-                    int precision, const void* target, int target_is_u8, const float* grad_logits, float* grads,
-                    float* loss, void* workspace, size_t workspace_bytes, void* stream) {
+                    int precision, float dropout_p, uint64_t dropout_seed, const void* target, int target_is_u8,
+                    const float* grad_logits, float* grads, float* loss, void* workspace, size_t workspace_bytes,
+                    void* stream) {
     Ctx c;
     if (int rc = init_ctx(c, cfg, params, batch, precision, workspace, workspace_bytes, stream)) return rc;
+    VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "dropout_p %f", dropout_p);
+    c.drop_p = dropout_p;
+    c.drop_seed = (unsigned)(dropout_seed ^ (dropout_seed >> 32));
     VITSEG_CHECK_ARG(x && grads, VITSEG_EINVAL, "x / grads is null");
     VITSEG_CHECK_ARG(!c.lp || params_bf16, VITSEG_EINVAL, "bf16 training needs the bf16 arena");
     c.params_lp = (const unsigned short*)params_bf16;
@@ -463,22 +502,32 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const void* p
     float* dQKV = c.T(c.p.dqkv);
     float* dCTX = c.T(c.p.dctx);
     for (int l = s.L - 1; l >= 0; --l) {
-        // MLP: Xout = Xmid + fc2(gelu(fc1(H2)))
-        if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
-        if ((rc = wgrad(dXa, c.L(l, c.p.lb.uact), G(VITSEG_T_W2, l), Mt, D, I))) return rc;
-        if ((rc = dgrad(dXa, c.W(VITSEG_T_W2, l), dU, Mt, D, I, EPI_DGELU, c.L(l, c.p.lb.upre)))) return rc;
+        // MLP: Xout = Xmid + drop(fc2(gelu(fc1(H2))))
+        const float* dB = dXa;  // gradient entering the (dropped) branch
+        if (c.drop_p > 0.f) {
+            if ((rc = launch_dropout_rows(dXa, c.T(c.p.dxm), 0, Mt, D, c.dr(l, 3), st))) return rc;
+            dB = c.T(c.p.dxm);
+        }
+        if ((rc = launch_colsum(dB, 0, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
+        if ((rc = wgrad(dB, c.L(l, c.p.lb.uact), G(VITSEG_T_W2, l), Mt, D, I))) return rc;
+        if ((rc = dgrad(dB, c.W(VITSEG_T_W2, l), dU, Mt, D, I, EPI_DGELU, c.L(l, c.p.lb.upre)))) return rc;
         if ((rc = launch_colsum(dU, 0, G(VITSEG_T_B1, l), scratch, Mt, I, I, st))) return rc;
         if ((rc = wgrad(dU, c.L(l, c.p.lb.h2), G(VITSEG_T_W1, l), Mt, I, D))) return rc;
         if ((rc = dgrad(dU, c.W(VITSEG_T_W1, l), dH, Mt, I, D, EPI_BIAS, nullptr))) return rc;
         if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xmid), c.W(VITSEG_T_LN2_W, l), dH, 0, dXa, dXb, G(VITSEG_T_LN2_W, l),
                                        G(VITSEG_T_LN2_B, l), scratch, Mt, D, c.eps, st)))
             return rc;
-        // attention: Xmid = Xin + o_proj(attn(qkv(H1)))
-        if ((rc = launch_colsum(dXb, 0, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
-        if ((rc = wgrad(dXb, c.L(l, c.p.lb.ctx), G(VITSEG_T_WO, l), Mt, D, D))) return rc;
-        if ((rc = dgrad(dXb, c.W(VITSEG_T_WO, l), dCTX, Mt, D, D, EPI_BIAS, nullptr))) return rc;
+        // attention: Xmid = Xin + drop(o_proj(attn(qkv(H1))))
+        dB = dXb;
+        if (c.drop_p > 0.f) {
+            if ((rc = launch_dropout_rows(dXb, c.T(c.p.dxm), 0, Mt, D, c.dr(l, 2), st))) return rc;
+            dB = c.T(c.p.dxm);
+        }
+        if ((rc = launch_colsum(dB, 0, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
+        if ((rc = wgrad(dB, c.L(l, c.p.lb.ctx), G(VITSEG_T_WO, l), Mt, D, D))) return rc;
+        if ((rc = dgrad(dB, c.W(VITSEG_T_WO, l), dCTX, Mt, D, D, EPI_BIAS, nullptr))) return rc;
         if ((rc = launch_attention_bwd_f32(c.L(l, c.p.lb.qkv), c.L(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
-                                           c.T(c.p.dvec), dQKV, B, s.Np, s.A, st)))
+                                           c.T(c.p.dvec), dQKV, B, s.Np, s.A, c.dr(l, 1), st)))
             return rc;
         if ((rc = launch_colsum(dQKV, 0, G(VITSEG_T_BQKV, l), scratch, Mt, 3 * D, 3 * D, st))) return rc;
         if ((rc = wgrad(dQKV, c.L(l, c.p.lb.h1), G(VITSEG_T_WQKV, l), Mt, 3 * D, D))) return rc;
@@ -488,6 +537,7 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const void* p
             return rc;
     }
     // ---- 5. embeddings ----
+    if (c.drop_p > 0.f && (rc = launch_dropout_rows(dXa, dXa, 0, Mt, D, c.dr(0, 0), st))) return rc;
     if ((rc = launch_embed_bwd(dXa, G(VITSEG_T_POS), G(VITSEG_T_CLS), B, s.Np, D, st))) return rc;
     if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_PATCH_B), scratch, Mp, D, D, st))) return rc;
     if ((rc = launch_im2col_patch(x, c.T(c.p.t), B, s.Cin, s.S, s.P, st))) return rc;

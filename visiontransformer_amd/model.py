@@ -31,11 +31,12 @@ class _LogitsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, arena, model, x):
         ctx.model, ctx.x = model, x
-        return model._forward_train(x, want_logits=True)
+        ctx.drop = model._next_dropout()
+        return model._forward_train(x, want_logits=True, drop=ctx.drop)
 
     @staticmethod
     def backward(ctx, dlogits):
-        grads, _ = ctx.model._backward(ctx.x, grad_logits=dlogits.to(torch.float32).contiguous())
+        grads, _ = ctx.model._backward(ctx.x, grad_logits=dlogits.to(torch.float32).contiguous(), drop=ctx.drop)
         return grads, None, None
 
 
@@ -44,8 +45,9 @@ class _CELossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, arena, model, x, target):
-        model._forward_train(x, want_logits=False)
-        grads, loss = model._backward(x, target=target)
+        drop = model._next_dropout()
+        model._forward_train(x, want_logits=False, drop=drop)
+        grads, loss = model._backward(x, target=target, drop=drop)
         ctx.grads = grads
         return loss
 
@@ -57,11 +59,16 @@ class _CELossFn(torch.autograd.Function):
 class ViTSegmentationModel(nn.Module):
     def __init__(self, num_classes, patch_size, hidden_size, num_hidden_layers, num_attention_heads, *,
                  image_size: int = 224, intermediate_size: int = 3072, precision: str = "fp32",
-                 device=None):
+                 dropout: float = 0.1, device=None):
         super().__init__()
         self.cfg = ViTSegConfig(num_classes, patch_size, hidden_size, num_hidden_layers, num_attention_heads,
                                 image_size=image_size, intermediate_size=intermediate_size)
         self.precision = _PRECISION[precision]
+        # hidden_dropout_prob = attention_probs_dropout_prob = 0.1 in the reference (classes.py:233-234); active only
+        # in train() mode with autograd on, like nn.Dropout.  `dropout_seed` + a step counter select the masks.
+        self.dropout = float(dropout)
+        self.dropout_seed = 0x5EED
+        self._dropout_step = 0
         n = _lib.param_count(self.cfg)  # validates the configuration (ValueError on unsupported shapes)
         self.arena = nn.Parameter(torch.zeros(n, dtype=torch.float32, device=device))
         self._views: Optional[Dict[str, torch.Tensor]] = None
@@ -201,7 +208,15 @@ class ViTSegmentationModel(nn.Module):
             self._ws = {key: ws}
         return ws
 
-    def _forward_train(self, x: torch.Tensor, want_logits: bool):
+    def _next_dropout(self):
+        """(p, seed) of the next training forward; p = 0 outside train() mode."""
+        if not self.training or self.dropout <= 0.0:
+            return (0.0, 0)
+        self._dropout_step += 1
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        return (self.dropout, (self.dropout_seed * 0x9E3779B97F4A7C15 + self._dropout_step * 0x100000001B3 + rank) & (2 ** 64 - 1))
+
+    def _forward_train(self, x: torch.Tensor, want_logits: bool, drop=(0.0, 0)):
         self._check_input(x)
         x = x.to(torch.float32).contiguous()
         B, S = x.shape[0], self.cfg.image_size
@@ -211,12 +226,12 @@ class ViTSegmentationModel(nn.Module):
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().vitseg_forward_train(
                 C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(), _ptr(self._bf16_arena()),
-                x.data_ptr(), B, self.precision, _ptr(logits), ws.data_ptr(), ws.numel(),
+                x.data_ptr(), B, self.precision, drop[0], drop[1], _ptr(logits), ws.data_ptr(), ws.numel(),
                 torch.cuda.current_stream().cuda_stream))
         return logits
 
     def _backward(self, x: torch.Tensor, target: Optional[torch.Tensor] = None,
-                  grad_logits: Optional[torch.Tensor] = None):
+                  grad_logits: Optional[torch.Tensor] = None, drop=(0.0, 0)):
         x = x.to(torch.float32).contiguous()
         B = x.shape[0]
         ws = self._train_workspace(B)
@@ -225,7 +240,7 @@ class ViTSegmentationModel(nn.Module):
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().vitseg_backward(
                 C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(), _ptr(self._bf16_arena()),
-                x.data_ptr(), B, self.precision,
+                x.data_ptr(), B, self.precision, drop[0], drop[1],
                 _ptr(target), int(target is not None and target.dtype == torch.uint8), _ptr(grad_logits),
                 grads.data_ptr(), _ptr(loss), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
         return grads, loss
@@ -236,7 +251,8 @@ class ViTSegmentationModel(nn.Module):
     # ------------------------------------------------------------------ reference surface
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """logits [B, C, H, W] (model/CE/classes.py:246-262).  Differentiable w.r.t. the parameters when
-        autograd is on (dropout p = 0; the backward runs in libvitseg, see vitseg_backward)."""
+        autograd is on (the backward runs in libvitseg, see vitseg_backward).  In train() mode dropout
+        (`self.dropout`, reference 0.1) is applied at the four HF sites with a counter-based generator."""
         if self._needs_grad():
             return _LogitsFn.apply(self.arena, self, x)
         logits, _ = self._run(x, True, False)
