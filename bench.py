@@ -40,14 +40,44 @@ KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
             "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0>",
             "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0>",
             "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
-    "bf16": {"gemm_bias": "gemm_kernel<unsigned short, unsigned short, 0, 0, 0, 0>",
-             "gemm_gelu": "gemm_kernel<unsigned short, unsigned short, 0, 1, 0, 0>",
+    "bf16": {"gemm_bias": "gemm_bf16_large_kernel<unsigned short, 0, 0, 256>",
+             "gemm_gelu": "gemm_bf16_large_kernel<unsigned short, 0, 1, 256>",
              "gemm_resadd": "gemm_kernel<unsigned short, float, 0, 2, 0, 0> (o_proj) + "
-                            "gemm_bf16_large_kernel<float, 0, 2> (fc2)",
+                            "gemm_bf16_large_kernel<float, 0, 2, 128> (fc2)",
              "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0>",
-             "gemm_conv3": "gemm_kernel<unsigned short, float, 2, 3, 0, 0>",
+             "gemm_conv3": "gemm_bf16_large_kernel<float, 2, 3, 128>",
              "attention": "attn_bf16_kernel<false> + attn_cls_bf16_kernel"},
 }
+
+
+def algorithmic_bytes(precision, kind, cfg, batch):
+    """Operand bytes one launch of the GEMM kind must move once (A + W + residual/bias + C), launch-averaged."""
+    D, I = cfg.hidden_size, cfg.intermediate_size
+    M = batch * ((cfg.image_size // cfg.patch_size) ** 2 + 1)
+    e = 4 if precision == "f32" else 2
+    shapes = {"gemm_bias": [(3 * D, D, e, 0)], "gemm_gelu": [(I, D, e, 0)],
+              "gemm_resadd": [(D, D, 4, 4), (D, I, 4, 4)]}.get(kind)   # (N, K, bytes of C, bytes of residual)
+    if not shapes:
+        return None
+    return round(sum(M * K * e + N * K * e + M * N * (c + r) + 4 * N for N, K, c, r in shapes) / len(shapes))
+
+
+def pmc_traffic(precision, kernel_label, batch):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_traffic.sh ->
+    tools/summarize_traffic.py -> profiles/r01_traffic_<prec>.json): counters cannot be read from inside this process,
+    so the figure is the one rocprofv3 measured on this same command (batch 32).  None when no pass covers the run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_traffic_{precision}.json")
+    if batch != 32 or not os.path.exists(path):
+        return None
+    kernels = json.load(open(path))["kernels"]
+    tot = n = 0.0
+    for part in kernel_label.split(" + "):
+        k = kernels.get(part.split(" (")[0].strip())
+        if k is None:
+            return None
+        tot += k["hbm_bytes_per_launch"] * k["launches_sampled"]
+        n += k["launches_sampled"]
+    return round(tot / n) if n else None
 
 
 def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.0):
@@ -223,7 +253,11 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "image_size": 512, "num_classes": 2,
                        "parallelism": f"batch-split x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4),
+                         "traffic": pmc_traffic(args.precision, KERNEL_NAMES[args.precision].get(dom, dom), B),
+                         "traffic_note": "L2-miss bytes/launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc passes in "
+                                         "profiles/); operand re-reads are served by the 256 MB Infinity Cache",
+                         "algorithmic_bytes_per_launch": algorithmic_bytes(args.precision, dom, cfg, B),
                          "kernel": KERNEL_NAMES[args.precision].get(dom, dom), "launches": d["launches"],
                          "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                          "flops_per_launch": d["work"] / max(d["launches"], 1)},

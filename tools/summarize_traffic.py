@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic per launch from the two PMC passes of tools/collect_traffic.sh.
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE is in KiB-like units of 1024 B and reports HALF the bytes
+of wide coalesced reads -> bytes_read = 2 * FETCH_SIZE * 1024; WRITE_SIZE * 1024 is exact for 16-B-per-lane stores."""
+import collections
+import csv
+import json
+import sys
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "f32"
+base = f"gpurun_out/traffic_{prec}"
+acc = collections.defaultdict(lambda: {"fetch": [], "write": []})
+for kind in ("fetch", "write"):
+    for r in csv.DictReader(open(f"{base}/{kind}/p_counter_collection.csv")):
+        name = r["Kernel_Name"]
+        if "vitseg" not in name:
+            continue
+        short = name.replace("(anonymous namespace)::", "").replace("vitseg::", "")
+        if short.endswith(")"):                      # drop the argument list, keep template arguments
+            depth = 0
+            for i in range(len(short) - 1, -1, -1):
+                depth += short[i] == ")"
+                depth -= short[i] == "("
+                if depth == 0:
+                    short = short[:i]
+                    break
+        short = short.replace("void ", "")
+        acc[short][kind].append(float(r["Counter_Value"]))
+out = {}
+for k, v in acc.items():
+    if not v["fetch"] or not v["write"]:
+        continue
+    rd = 2.0 * 1024.0 * sum(v["fetch"]) / len(v["fetch"])
+    wr = 1024.0 * sum(v["write"]) / len(v["write"])
+    out[k] = {"launches_sampled": len(v["fetch"]), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+              "hbm_bytes_per_launch": rd + wr}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2; "
+                     "read = 2 * FETCH_SIZE * 1024 (gfx950 wide-read correction), write = WRITE_SIZE * 1024",
+           "precision": prec, "kernels": out}, open(f"profiles/r01_traffic_{prec}.json", "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
+    print(f"{k[:70]:70s} read {v['read_bytes_per_launch']/1e6:9.1f} MB  write {v['write_bytes_per_launch']/1e6:9.1f} MB  x{v['launches_sampled']}")

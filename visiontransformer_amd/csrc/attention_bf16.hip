@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    const AttnTile at = attn_tile((Np + QB - 1) / QB, A);
+    const int head = at.head, b = at.b;
     const int D = A * HD, ld = 3 * D;
     const size_t row0 = (size_t)b * Np;
     const size_t cls_row = (size_t)B * Np + b;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
     const float c = 0.125f * LOG2E;
 
     // ---- this lane's query row: k-step s holds Q[16 s + 8 lh .. +7] (B operand of S^T) ----
-    const int q_local = blockIdx.x * QB + wave * 32 + li;
+    const int q_local = at.rt * QB + wave * 32 + li;
     const bool q_valid = q_local < Np;
     const size_t q_row = row0 + (q_valid ? q_local : Np - 1);
     f32x4 qf[4];
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __res
 
 int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_bf16: bad arguments");
-    const dim3 grid((Np + QB - 1) / QB, A, B);
+    const dim3 grid((unsigned)((Np + QB - 1) / QB) * A * B);  // 1-D: attn_tile() places the tiles
     if (Np % QB == 0)
         hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B, Np,
                            A, dr);

@@ -66,13 +66,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][TT * HD];  // [buffer][K|V]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    const AttnTile at = attn_tile((Np + 1 + TB - 1) / TB, A);
+    const int head = at.head, b = at.b;
     const int D = A * HD, ld = 3 * D, N = Np + 1;
     const bf16_t* kbase = qkv + D + head * HD;
     const bf16_t* vbase = qkv + 2 * D + head * HD;
     const float c = 0.125f * LOG2E;
 
-    const int nq = blockIdx.x * TB + wave * 32 + li;
+    const int nq = at.rt * TB + wave * 32 + li;
     const bool q_valid = nq < N;
     const size_t q_row = tok_row(b, q_valid ? nq : 0, B, Np);
     f32x4 qf[4], dof[4];
@@ -186,11 +187,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
     __shared__ float stats[2][2][TT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    const AttnTile at = attn_tile((Np + 1 + TB - 1) / TB, A);
+    const int head = at.head, b = at.b;
     const int D = A * HD, ld = 3 * D, N = Np + 1;
     const float c = 0.125f * LOG2E;
 
-    const int nk = blockIdx.x * TB + wave * 32 + li;
+    const int nk = at.rt * TB + wave * 32 + li;
     const bool k_valid = nk < N;
     const size_t k_row = tok_row(b, k_valid ? nk : 0, B, Np);
     f32x4 kf[4], vf[4];
@@ -319,7 +321,7 @@ int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, (const bf16_t*)ctx,
                        (const bf16_t*)dctx, dvec, B, Np, A);
     VITSEG_LAUNCH_CHECK("attn_delta_bf16");
-    const dim3 grid((N + TB - 1) / TB, A, B);
+    const dim3 grid((unsigned)((N + TB - 1) / TB) * A * B);  // 1-D: attn_tile() places the tiles
     hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec,
                        (bf16_t*)dqkv, B, Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_bwd_dq_bf16");

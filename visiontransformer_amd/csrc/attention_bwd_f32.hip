@@ -52,13 +52,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) float lds[2][2][TT * HD];  // [buffer][K|V]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    const AttnTile at = attn_tile((Np + 1 + TB - 1) / TB, A);
+    const int head = at.head, b = at.b;
     const int D = A * HD, ld = 3 * D, N = Np + 1;
     const float* kbase = qkv + D + head * HD;
     const float* vbase = qkv + 2 * D + head * HD;
     const float c = 0.125f * LOG2E;
 
-    const int nq = blockIdx.x * TB + wave * 32 + li;
+    const int nq = at.rt * TB + wave * 32 + li;
     const bool q_valid = nq < N;
     const size_t q_row = tok_row(b, q_valid ? nq : 0, B, Np);
     float qreg[32], doreg[32];  // element 4c+e = X[8c + 4 lh + e]
@@ -180,11 +181,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
     __shared__ float stats[2][2][TT];                                  // [buffer][lse|delta]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    const AttnTile at = attn_tile((Np + 1 + TB - 1) / TB, A);
+    const int head = at.head, b = at.b;
     const int D = A * HD, ld = 3 * D, N = Np + 1;
     const float c = 0.125f * LOG2E;
 
-    const int nk = blockIdx.x * TB + wave * 32 + li;
+    const int nk = at.rt * TB + wave * 32 + li;
     const bool k_valid = nk < N;
     const size_t k_row = tok_row(b, k_valid ? nk : 0, B, Np);
     float kreg[32], vreg[32];
@@ -320,7 +322,7 @@ int launch_attention_bwd_f32(const float* qkv, const float* ctx, const float* dc
     const size_t items = (size_t)B * A * N;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, ctx, dctx, dvec, B, Np, A);
     VITSEG_LAUNCH_CHECK("attn_delta");
-    const dim3 grid((N + TB - 1) / TB, A, B);
+    const dim3 grid((unsigned)((N + TB - 1) / TB) * A * B);  // 1-D: attn_tile() places the tiles
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_bwd_dq");
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    const AttnTile at = attn_tile((Np + QB - 1) / QB, A);
+    const int head = at.head, b = at.b;
     const int D = A * HD, ld = 3 * D;
     const size_t row0 = (size_t)b * Np;           // first patch row of this image
     const size_t cls_row = (size_t)B * Np + b;    // CLS row of this image
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
     const float* vbase = qkv + 2 * D + head * HD;
 
     // ---- this lane's query row, pre-scaled by hd^-0.5 * log2(e) (scores live in log2 units) ----
-    const int q_local = blockIdx.x * QB + wave * 32 + li;
+    const int q_local = at.rt * QB + wave * 32 + li;
     const bool q_valid = q_local < Np;
     const size_t q_row = row0 + (q_valid ? q_local : Np - 1);
     const float qscale = 0.125f * LOG2E;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(1024) void attn_cls_f32_kernel(const float* __restr
 
 int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_f32: bad arguments");
-    const dim3 grid((Np + QB - 1) / QB, A, B);
+    const dim3 grid((unsigned)((Np + QB - 1) / QB) * A * B);  // 1-D: attn_tile() places the tiles
     if (Np % QB == 0)
         hipLaunchKernelGGL(attn_f32_kernel<false>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr);
     else

@@ -41,6 +41,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Attention grids are 1-D: block -> (row tile, head, image) with all row tiles of one (image, head) pair on ONE XCD and
+// resident together, so its K/V (or Q/dO) panels are fetched into a single L2 once.  (With a 3-D grid the hardware
+// deals the tiles of a pair round-robin over the 8 XCDs: measured 5.7x over-fetch, profiles/r01_traffic_f32.json.)
+struct AttnTile {
+    int rt, head, b;
+};
+__device__ __forceinline__ AttnTile attn_tile(int ntiles, int A) {
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = t / ntiles;
+    AttnTile r;
+    r.rt = t - bh * ntiles;
+    r.b = bh / A;
+    r.head = bh - r.b * A;
+    return r;
+}
+
 // ---- dropout: counter-based keep/drop decision (no state, identical in forward and backward) ----
 // keep(seed, stream, major, minor) = fmix32(minor ^ fmix32(seed ^ stream*C1 ^ major*C2)) >= thresh, thresh = p * 2^32.
 // `stream` = layer * 8 + site (0 embeddings, 1 attention probabilities, 2 attention output, 3 MLP output);

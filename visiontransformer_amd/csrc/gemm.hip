@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     //     group's W panel (GN*128 rows of K) stays in the 4 MiB L2 while the A panels stream past it.
     //     (n-fastest order measured 62 % L2 hit rate / 16x over-fetch on the N = 3072 GEMM.)
     int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int GN = (size_t)p.K * sizeof(T) <= 2048 ? 8 : 4;
+    const int GN = p.gn ? p.gn : 8;  // 4/8/16 time within 1.5 % of each other (tools/gn_sweep.sh); 8 fetches least
     const bool thin_last = p.M - (tiles_m - 1) * BM <= 64 && tiles_m > 1;
     int tile_m, tile_n;
     if (thin_last && t < tiles_n) {
@@ -471,9 +471,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         gemm_tile<T, OutT, AMODE, EPI, 2, 2, TA, TB>(p, lds, m0, n0, (wave >> 1) * 64, (wave & 1) * 64);
 }
 
+inline int env_gn() {  // experiments only: VITSEG_GN=<n> forces the column-group width of the tile order
+    static const int v = [] { const char* e = getenv("VITSEG_GN"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <typename T, typename OutT, int AMODE, int EPI, int TA = 0, int TB = 0>
 int launch_one(GemmArgs a, hipStream_t s) {
     if (a.ldw == 0) a.ldw = TB ? a.N : a.K;
+    if (!a.gn) a.gn = env_gn();
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int splits = a.splitk > 1 ? a.splitk : 1;
     hipLaunchKernelGGL((gemm_kernel<T, OutT, AMODE, EPI, TA, TB>), dim3(tiles, splits), dim3(256), 0, s, a);
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
     const int wm = LBN == 128 ? wave >> 1 : wave >> 2, wn = LBN == 128 ? wave & 1 : wave & 3;
     const int tiles_n = (p.N + LBN - 1) / LBN, tiles_m = (p.M + LBM - 1) / LBM;
     int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int GN = LBN == 128 ? ((size_t)p.K * sizeof(T) <= 2048 ? 8 : 4) : 4;
+    const int GN = p.gn ? p.gn : (LBN == 128 ? ((size_t)p.K * sizeof(T) <= 2048 ? 8 : 4) : 4);
     const bool thin_last = p.M - (tiles_m - 1) * LBM <= 64 && tiles_m > 1;
     int tile_m, tile_n;
     if (thin_last && t < tiles_n) {
@@ -762,6 +768,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
 template <typename OutT, int AMODE, int EPI, int LBN = 128>
 int launch_large(GemmArgs a, hipStream_t s) {
     if (a.ldw == 0) a.ldw = a.K;
+    if (!a.gn) a.gn = env_gn();
     const int tiles = ((a.M + LBM - 1) / LBM) * ((a.N + LBN - 1) / LBN);
     const size_t smem = (size_t)(LBN == 128 ? 3 : 2) * (LBM + LBN) * BKF * sizeof(float);  // 144 / 128 KiB
     static bool attr_set = false;

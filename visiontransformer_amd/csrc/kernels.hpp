@@ -36,6 +36,7 @@ struct GemmArgs {
     const void* zeros;  // >= 128 zero bytes (bf16 A_CONV3: source of the padding taps)
     int splitk;           // > 1: grid.y slices of the K range, each writing C + y * split_stride
     size_t split_stride;
+    int gn;               // column-group width of the tile order (0 = pick from K; VITSEG_GN overrides for experiments)
     DropArgs drop;        // EPI_RESADD: C = R + dropout(acc + bias)   (hidden dropout, modeling_vit.py:276,283)
 };
 
