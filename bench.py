@@ -117,7 +117,7 @@ def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.
 def bench_train(args, cfg, model, x, rank, world, dev, barrier):
     """One step = LightningViTModel.training_step + backward + (N>1: RCCL all-reduce of the flat gradient
     arena) + Adam(lr=1e-5): BASELINE configs[2]/[3] (--precision bf16 = mixed precision, --batch 64)."""
-    from visiontransformer_amd.dist import allreduce_grads
+    from visiontransformer_amd.dist import sync_grads
     from visiontransformer_amd.optim import FusedAdam
     B = args.batch
     y = torch.from_numpy(synth.make_targets(cfg, B, seed=0, first_image=rank * B, size=cfg.image_size)).to(dev)
@@ -128,7 +128,7 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
         opt.zero_grad(set_to_none=True)
         loss = model.ce_loss(x, y)
         loss.backward()
-        allreduce_grads(model.arena.grad)
+        sync_grads(model)
         opt.step(grad_scale=1.0 / world)
         return loss
 
@@ -159,7 +159,7 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
             "config": {"workload": f"ViT-B/16 seg TRAINING step (forward + CE + backward + Adam), batch {B}/GPU x "
                                    f"512x512, {args.precision}, dropout {model.dropout} (reference: 0.1)", "batch_per_gpu": B,
                        "global_batch": B * world,
-                       "parallelism": f"data-parallel x{world}, flat-arena gradient all-reduce (RCCL)"},
+                       "parallelism": f"data-parallel x{world}, bucketed gradient all-reduce (RCCL) overlapped with the backward"},
             "whole_model": {"flops_per_image": flops_img,
                             "achieved_tflops_per_gpu": round(value / world * flops_img / 1e12, 2),
                             "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},

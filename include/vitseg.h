@@ -166,8 +166,17 @@ int vitseg_forward_train(const vitseg_config* cfg, const float* params, const vo
                          void* workspace, size_t workspace_bytes, void* stream);
 int vitseg_backward(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x, int batch,
                     int precision, float dropout_p, uint64_t dropout_seed, const void* target, int target_is_u8,
-                    const float* grad_logits, float* grads, float* loss, void* workspace, size_t workspace_bytes,
-                    void* stream);
+                    const float* grad_logits, float* grads, float* loss, void* const* bucket_events, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* Gradient buckets for overlapping the data-parallel all-reduce with the backward (the reference
+ * trains single-process, this replaces what DDP would do behind trainer.fit, trainCurrentViTmodel.py:97-101).
+ * The gradient arena splits into vitseg_grad_bucket_count() = L + 2 contiguous ranges in the order the backward
+ * finishes them: 0 = final norm + seg_head, 1 .. L = encoder layers L-1 .. 0, L + 1 = embeddings.
+ * vitseg_backward records bucket_events[i] (hipEvent_t, created by the caller; NULL array or NULL entries = skip)
+ * on `stream` right after the last kernel that writes bucket i, so a communication stream can wait on it and
+ * reduce that range while the rest of the backward still runs. */
+int vitseg_grad_bucket_count(const vitseg_config* cfg);
+int vitseg_grad_bucket_range(const vitseg_config* cfg, int bucket, size_t* offset_floats, size_t* n_floats);
 /* one Adam step over a flat fp32 buffer (torch.optim.Adam semantics, weight_decay 0, amsgrad off);
  * step is 1-based; gradients are multiplied by grad_scale first (1/world for summed all-reduce). */
 int vitseg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n_floats, float lr,

@@ -28,6 +28,7 @@ EXPORTS = [
     "vitseg_profile_enable", "vitseg_profile_collect", "vitseg_op_linear_bf16", "vitseg_op_attention_bf16",
     "vitseg_ce_scratch_bytes", "vitseg_ce_loss",
     "vitseg_train_workspace", "vitseg_forward_train", "vitseg_backward", "vitseg_adam_step",
+    "vitseg_grad_bucket_count", "vitseg_grad_bucket_range",
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
@@ -79,7 +80,9 @@ def lib() -> C.CDLL:
         f32 = C.c_float
         l.vitseg_train_workspace.argtypes = [pcfg, i32, i32, psz]
         l.vitseg_forward_train.argtypes = [pcfg, vp, vp, vp, i32, i32, f32, C.c_uint64, vp, vp, sz, vp]
-        l.vitseg_backward.argtypes = [pcfg, vp, vp, vp, i32, i32, f32, C.c_uint64, vp, i32, vp, vp, vp, vp, sz, vp]
+        l.vitseg_backward.argtypes = [pcfg, vp, vp, vp, i32, i32, f32, C.c_uint64, vp, i32, vp, vp, vp, vp, vp, sz, vp]
+        l.vitseg_grad_bucket_count.argtypes = [pcfg]
+        l.vitseg_grad_bucket_range.argtypes = [pcfg, i32, psz, psz]
         l.vitseg_adam_step.argtypes = [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, f32, vp]
         l.vitseg_op_gemm_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
@@ -132,6 +135,21 @@ def train_workspace(cfg: ViTSegConfig, batch: int, precision: int) -> int:
     n = C.c_size_t()
     check(lib().vitseg_train_workspace(C.byref(CConfig.from_config(cfg)), batch, precision, C.byref(n)))
     return n.value
+
+
+def grad_buckets(cfg: ViTSegConfig) -> list:
+    """[(offset_floats, n_floats)] of the gradient arena in the order vitseg_backward finishes them
+    (0 = final norm + seg_head, 1 .. L = layers L-1 .. 0, L + 1 = embeddings)."""
+    c = CConfig.from_config(cfg)
+    n = lib().vitseg_grad_bucket_count(C.byref(c))
+    if n < 0:
+        check(n)
+    out = []
+    for i in range(n):
+        off, cnt = C.c_size_t(), C.c_size_t()
+        check(lib().vitseg_grad_bucket_range(C.byref(c), i, C.byref(off), C.byref(cnt)))
+        out.append((off.value, cnt.value))
+    return out
 
 
 def profile_enable(on: bool) -> None:

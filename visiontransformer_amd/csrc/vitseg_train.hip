@@ -109,6 +109,13 @@ TrainPlan make_train_plan(const Shape& s, int B, int precision) {
 }
 
 struct Ctx {
+    void* const* events = nullptr;  // optional hipEvent_t per gradient bucket (vitseg_backward)
+    // records bucket event i on the launch stream: every gradient of that bucket is final at this point
+    int mark(int bucket) const {
+        if (!events || !events[bucket]) return VITSEG_OK;
+        hipError_t e = hipEventRecord((hipEvent_t)events[bucket], st);
+        return e == hipSuccess ? VITSEG_OK : hip_fail(e, "hipEventRecord(grad bucket)");
+    }
     Shape s;
     TrainPlan p;
     Layout lay;
@@ -295,6 +302,7 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
     if ((rc = launch_layernorm_bwd(c.T(c.p.xfinal), c.W(VITSEG_T_LNF_W), dHf, 0, nullptr, dXa, G(VITSEG_T_LNF_W),
                                    G(VITSEG_T_LNF_B), scratch, Mp, D, c.eps, st)))
         return rc;
+    if ((rc = c.mark(0))) return rc;  // bucket 0: final norm + seg_head
     // ---- 4. encoder layers ----
     void *dH = c.TV(c.p.dh), *dU = c.TV(c.p.du), *dQKV = c.TV(c.p.dqkv), *dCTX = c.TV(c.p.dctx);
     for (int l = s.L - 1; l >= 0; --l) {
@@ -331,6 +339,7 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
         if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xin), c.W(VITSEG_T_LN1_W, l), dH, 1, dXb, dXa, G(VITSEG_T_LN1_W, l),
                                        G(VITSEG_T_LN1_B, l), scratch, Mt, D, c.eps, st)))
             return rc;
+        if ((rc = c.mark(s.L - l))) return rc;  // bucket 1 + (L-1-l): layer l
     }
     // ---- 5. embeddings (fp32) ----
     if (c.drop_p > 0.f && (rc = launch_dropout_rows(dXa, dXa, 0, Mt, D, c.dr(0, 0), st))) return rc;
@@ -339,7 +348,8 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
     if ((rc = launch_im2col_patch(x, c.T(c.p.t), B, s.Cin, s.S, s.P, st))) return rc;
     GemmArgs g = lin(dXa, c.T(c.p.t), nullptr, nullptr, G(VITSEG_T_PATCH_W), D, s.Kp, Mp, D, s.Kp);
     g.ldw = s.Kp;
-    return launch_wgrad_f32(g, c.T(c.p.wscratch), st);
+    if ((rc = launch_wgrad_f32(g, c.T(c.p.wscratch), st))) return rc;
+    return c.mark(s.L + 1);  // last bucket: embeddings
 }
 
 }  // namespace
@@ -422,9 +432,10 @@ int vitseg_forward_train(const vitseg_config* cfg, const float* params, const vo
 
 int vitseg_backward(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x, int batch,
                     int precision, float dropout_p, uint64_t dropout_seed, const void* target, int target_is_u8,
-                    const float* grad_logits, float* grads, float* loss, void* workspace, size_t workspace_bytes,
-                    void* stream) {
+                    const float* grad_logits, float* grads, float* loss, void* const* bucket_events, void* workspace,
+                    size_t workspace_bytes, void* stream) {
     Ctx c;
+    c.events = bucket_events;
     if (int rc = init_ctx(c, cfg, params, batch, precision, workspace, workspace_bytes, stream)) return rc;
     VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "dropout_p %f", dropout_p);
     c.drop_p = dropout_p;
@@ -496,6 +507,7 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const void* p
     if ((rc = launch_layernorm_bwd(c.T(c.p.xfinal), c.W(VITSEG_T_LNF_W), dH, 0, nullptr, dXa, G(VITSEG_T_LNF_W),
                                    G(VITSEG_T_LNF_B), scratch, Mp, D, c.eps, st)))
         return rc;
+    if ((rc = c.mark(0))) return rc;  // bucket 0: final norm + seg_head
 
     // ---- 4. encoder layers, last to first ----
     float* dU = c.T(c.p.du);
@@ -535,13 +547,41 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const void* p
         if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xin), c.W(VITSEG_T_LN1_W, l), dH, 0, dXb, dXa, G(VITSEG_T_LN1_W, l),
                                        G(VITSEG_T_LN1_B, l), scratch, Mt, D, c.eps, st)))
             return rc;
+        if ((rc = c.mark(s.L - l))) return rc;  // bucket 1 + (L-1-l): layer l
     }
     // ---- 5. embeddings ----
     if (c.drop_p > 0.f && (rc = launch_dropout_rows(dXa, dXa, 0, Mt, D, c.dr(0, 0), st))) return rc;
     if ((rc = launch_embed_bwd(dXa, G(VITSEG_T_POS), G(VITSEG_T_CLS), B, s.Np, D, st))) return rc;
     if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_PATCH_B), scratch, Mp, D, D, st))) return rc;
     if ((rc = launch_im2col_patch(x, c.T(c.p.t), B, s.Cin, s.S, s.P, st))) return rc;
-    return wgrad(dXa, c.T(c.p.t), G(VITSEG_T_PATCH_W), Mp, D, s.Kp);
+    if ((rc = wgrad(dXa, c.T(c.p.t), G(VITSEG_T_PATCH_W), Mp, D, s.Kp))) return rc;
+    return c.mark(s.L + 1);  // last bucket: embeddings
+}
+
+int vitseg_grad_bucket_count(const vitseg_config* cfg) {
+    Shape s;
+    if (int rc = check_config(cfg, &s)) return rc;
+    return s.L + 2;
+}
+
+int vitseg_grad_bucket_range(const vitseg_config* cfg, int bucket, size_t* offset_floats, size_t* n_floats) {
+    Shape s;
+    if (int rc = check_config(cfg, &s)) return rc;
+    VITSEG_CHECK_ARG(bucket >= 0 && bucket < s.L + 2 && offset_floats && n_floats, VITSEG_EINVAL,
+                     "grad bucket %d out of [0, %d)", bucket, s.L + 2);
+    const Layout lay = make_layout(s);
+    const size_t post0 = lay.layer0 + lay.layer_stride * s.L;
+    if (bucket == 0) {
+        *offset_floats = post0;
+        *n_floats = lay.total - post0;
+    } else if (bucket <= s.L) {
+        *offset_floats = lay.layer0 + (size_t)(s.L - bucket) * lay.layer_stride;
+        *n_floats = lay.layer_stride;
+    } else {
+        *offset_floats = 0;
+        *n_floats = lay.layer0;
+    }
+    return VITSEG_OK;
 }
 
 int vitseg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n_floats, float lr,

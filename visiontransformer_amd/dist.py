@@ -81,3 +81,53 @@ def allreduce_grads(flat_grad: torch.Tensor, bucket_mb: float = 64.0) -> None:
         hi = lo
     for w in works:
         w.wait()
+
+
+class BucketReducer:
+    """Gradient all-reduce overlapped with the backward.
+
+    `ranges` are the arena ranges in the order `vitseg_backward` finishes them (`_lib.grad_buckets`: head, layers
+    L-1 .. 0, embeddings); consecutive ones are merged until a message reaches `min_mb` -- they are adjacent in
+    the arena, so a merged bucket is still one contiguous slice and one RCCL call (xGMI rings are per-link
+    bound: few large messages).  `reduce()` issues one asynchronous all-reduce per bucket; on the GPU each is
+    enqueued behind the event the backward records when that bucket's last gradient kernel has been launched
+    (`events[i]`), on a side stream, so the ring for layer l runs while layers l-1 .. 0 are still computing."""
+
+    def __init__(self, ranges, min_mb: float = 48.0, elem_bytes: int = 4):
+        self.ranges = list(ranges)
+        self.groups = []  # (lo, hi, index of the bucket whose event completes the group)
+        lo = hi = None
+        for i, (off, n) in enumerate(self.ranges):
+            if lo is None:
+                lo, hi = off, off + n
+            else:
+                if off + n != lo and off != hi:
+                    raise ValueError("gradient buckets are not adjacent in the arena")
+                lo, hi = min(lo, off), max(hi, off + n)
+            if (hi - lo) * elem_bytes >= min_mb * (1 << 20) or i == len(self.ranges) - 1:
+                self.groups.append((lo, hi, i))
+                lo = hi = None
+
+    def reduce(self, flat: torch.Tensor, events=None, comm_stream=None, group=None):
+        """Starts the all-reduces (sum) of every bucket of `flat`; returns the work handles (wait() on each before
+        the gradients are read).  With `events` (one torch.cuda.Event per range) bucket i is reduced on
+        `comm_stream` as soon as events[last range of i] has fired on the compute stream."""
+        works = []
+        for lo, hi, last in self.groups:
+            piece = flat[lo:hi]
+            if events is not None:
+                comm_stream.wait_event(events[last])
+                with torch.cuda.stream(comm_stream):
+                    works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            else:
+                works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        return works
+
+
+def sync_grads(model) -> None:
+    """Makes `model.arena.grad` the SUM over ranks: a no-op when the backward already reduced it bucket by bucket
+    (`model.grad_sync == "overlap"`), else the flat all-reduce above.  Callers then step with grad_scale=1/world."""
+    if getattr(model, "_grads_reduced", False):
+        model._grads_reduced = False
+        return
+    allreduce_grads(model.arena.grad)

@@ -69,6 +69,12 @@ class ViTSegmentationModel(nn.Module):
         self.dropout = float(dropout)
         self.dropout_seed = 0x5EED
         self._dropout_step = 0
+        # data-parallel gradient exchange: "overlap" = bucketed all-reduce behind events inside the backward,
+        # "after" = one flat all-reduce by the caller (dist.allreduce_grads), see dist.sync_grads
+        self.grad_sync = "overlap"
+        self.grad_bucket_mb = 48.0
+        self._buckets = None
+        self._grads_reduced = False
         n = _lib.param_count(self.cfg)  # validates the configuration (ValueError on unsupported shapes)
         self.arena = nn.Parameter(torch.zeros(n, dtype=torch.float32, device=device))
         self._views: Optional[Dict[str, torch.Tensor]] = None
@@ -230,6 +236,25 @@ class ViTSegmentationModel(nn.Module):
                 torch.cuda.current_stream().cuda_stream))
         return logits
 
+    def _overlap_active(self) -> bool:
+        """Bucketed all-reduce inside the backward: "overlap" = whenever a process group with > 1 rank exists,
+        "force" = also with one rank (tests), "after" = never (callers use dist.allreduce_grads)."""
+        import torch.distributed as td
+        if self.grad_sync == "force":
+            return td.is_available() and td.is_initialized()
+        return self.grad_sync == "overlap" and td.is_available() and td.is_initialized() and td.get_world_size() > 1
+
+    def _bucket_state(self):
+        if self._buckets is None:
+            from .dist import BucketReducer
+            ranges = _lib.grad_buckets(self.cfg)
+            events = [torch.cuda.Event() for _ in ranges]
+            for e in events:
+                e.record()  # instantiates the hipEvent_t so its handle can cross the C ABI
+            handles = (C.c_void_p * len(events))(*[e.cuda_event for e in events])
+            self._buckets = (BucketReducer(ranges, self.grad_bucket_mb), events, handles, torch.cuda.Stream())
+        return self._buckets
+
     def _backward(self, x: torch.Tensor, target: Optional[torch.Tensor] = None,
                   grad_logits: Optional[torch.Tensor] = None, drop=(0.0, 0)):
         x = x.to(torch.float32).contiguous()
@@ -237,12 +262,21 @@ class ViTSegmentationModel(nn.Module):
         ws = self._train_workspace(B)
         grads = torch.empty_like(self.arena.data)
         loss = torch.zeros((), dtype=torch.float32, device=x.device) if target is not None else None
+        overlap = self._overlap_active()
         with torch.cuda.device(x.device):
+            reducer, events, handles, comm = self._bucket_state() if overlap else (None, None, None, None)
             _lib.check(_lib.lib().vitseg_backward(
                 C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(), _ptr(self._bf16_arena()),
                 x.data_ptr(), B, self.precision, drop[0], drop[1],
                 _ptr(target), int(target is not None and target.dtype == torch.uint8), _ptr(grad_logits),
-                grads.data_ptr(), _ptr(loss), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+                grads.data_ptr(), _ptr(loss), handles, ws.data_ptr(), ws.numel(),
+                torch.cuda.current_stream().cuda_stream))
+            if overlap:
+                # the whole backward is enqueued by now; each ring starts when its bucket's event fires and the
+                # compute stream only rejoins after the last one (what DDP's finalize does)
+                for w in reducer.reduce(grads, events, comm):
+                    w.wait()
+                self._grads_reduced = True
         return grads, loss
 
     def _needs_grad(self) -> bool:

@@ -15,7 +15,7 @@ from typing import Iterable, Optional
 import torch
 import torch.distributed as dist
 
-from .dist import allreduce_grads
+from .dist import sync_grads
 from .lightning import LightningViTModel
 
 
@@ -41,7 +41,7 @@ def fit(model: LightningViTModel, train_batches: Iterable, val_batches: Optional
             ep_loss += float(loss.detach())
             n_micro += 1
             if n_micro % accumulate_grad_batches == 0:
-                allreduce_grads(model.model.arena.grad)
+                sync_grads(model.model)
                 opt.step(grad_scale=1.0 / world)
                 opt.zero_grad(set_to_none=True)
                 step += 1
