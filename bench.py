@@ -34,19 +34,28 @@ from visiontransformer_amd import _lib, synth  # noqa: E402
 from visiontransformer_amd.config import vit_base16  # noqa: E402
 from visiontransformer_amd.model import ViTSegmentationModel  # noqa: E402
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
 KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
     "f32": {"gemm_bias": "gemm_kernel<float, float, 0, 0, 0, 0>", "gemm_gelu": "gemm_kernel<float, float, 0, 1, 0, 0>",
             "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0>",
             "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0>",
             "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
-    "bf16": {"gemm_bias": "gemm_bf16_large_kernel<unsigned short, 0, 0, 256>",
-             "gemm_gelu": "gemm_bf16_large_kernel<unsigned short, 0, 1, 256>",
+    "bf16": {"gemm_bias": "gemm_bf16_large_kernel<unsigned short, unsigned short, 0, 0, 256>",
+             "gemm_gelu": "gemm_bf16_large_kernel<unsigned short, unsigned short, 0, 1, 256>",
              "gemm_resadd": "gemm_kernel<unsigned short, float, 0, 2, 0, 0> (o_proj) + "
-                            "gemm_bf16_large_kernel<float, 0, 2, 128> (fc2)",
+                            "gemm_bf16_large_kernel<unsigned short, float, 0, 2, 128> (fc2)",
              "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0>",
-             "gemm_conv3": "gemm_bf16_large_kernel<float, 2, 3, 128>",
-             "attention": "attn_bf16_kernel<false> + attn_cls_bf16_kernel"},
+             "gemm_conv3": "gemm_bf16_large_kernel<unsigned short, float, 2, 3, 128>",
+             "attention": "attn_bf16_kernel<false, unsigned short> + attn_cls_bf16_kernel<unsigned short>"},
+    # rocprofv3's demangler does not know _Float16 (DF16_): the IEEE-half instantiations appear mangled in its CSVs
+    "f16": {"gemm_bias": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_DF16_Li0ELi0ELi256EEEvNS_8GemmArgsE",
+            "gemm_gelu": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_DF16_Li0ELi1ELi256EEEvNS_8GemmArgsE",
+            "gemm_resadd": "_ZN6vitseg12_GLOBAL__N_111gemm_kernelIDF16_fLi0ELi2ELi0ELi0EEEvNS_8GemmArgsE (o_proj) + "
+                           "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi0ELi2ELi128EEEvNS_8GemmArgsE (fc2)",
+            "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0>",
+            "gemm_conv3": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi2ELi3ELi128EEEvNS_8GemmArgsE",
+            "attention": "_ZN6vitseg12_GLOBAL__N_116attn_bf16_kernelILb0EDF16_EEvPKtPtPfiiiNS_8DropArgsE + "
+                         "_ZN6vitseg12_GLOBAL__N_120attn_cls_bf16_kernelIDF16_EEvPKtPtPfiiiNS_8DropArgsE"},
 }
 
 
@@ -114,6 +123,75 @@ def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.
     return base, parity
 
 
+def bench_tiled(args, rank, world, dev, barrier):
+    """BASELINE configs[4]: ViT-L/16 seg inference on 1024x1024 inputs as four 512x512 tiles through an
+    image_size=512 model (build-defined tiling), fp16 operands by default; `--batch` 1024^2 images per
+    GPU (16 = the config's 128 over 8 GPUs).  Mask-only output, so the decoder tail writes 1 B/pixel."""
+    from visiontransformer_amd.config import vit_large16
+    cfg = vit_large16(num_classes=2, image_size=512)
+    B = args.batch
+    model = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+                                 cfg.num_attention_heads, image_size=512,
+                                 precision={"f32": "fp32", "bf16": "bf16", "f16": "fp16"}[args.precision], device=dev).eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=1).items()})
+    tiles = torch.from_numpy(synth.make_images(cfg, 4 * B, seed=0, first_image=rank * 4 * B)).to(dev)
+    x = tiles.reshape(B, 2, 2, 3, 512, 512).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 1024, 1024).contiguous()
+    del tiles
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            mask = model.predict_mask_tiled(x)
+        torch.cuda.synchronize()
+        barrier()
+        _lib.profile_enable(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mask = model.predict_mask_tiled(x)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        flops_img = 4.0 * cfg.forward_flops_per_image()
+        peak = PEAK_TFLOPS[args.precision]
+        mfma = {k: v for k, v in prof.items() if k.startswith("gemm") or k == "attention"}
+        dom = max(mfma, key=lambda k: mfma[k]["ms"])
+        d = mfma[dom]
+        achieved = d["work"] / (d["ms"] * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "images/sec (1024x1024 as 4 tiles of 512x512) ViT-L/16 seg",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"ViT-L/16 seg inference, {B} x 1024x1024 per GPU tiled 4 x 512x512, {args.precision}, "
+                                   f"uint8 mask output (BASELINE.json configs[4])", "batch_per_gpu": B,
+                       "global_batch": B * world, "tiles_per_step": 4 * B, "mask_positive_fraction": float(mask.float().mean()),
+                       "parallelism": f"batch-split x{world}, no collective"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "kernel": KERNEL_NAMES[args.precision].get(dom, dom), "launches": d["launches"],
+                         "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
+                         "flops_per_launch": d["work"] / max(d["launches"], 1)},
+            "whole_model": {"flops_per_image": flops_img,
+                            "achieved_tflops_per_gpu": round(value / world * flops_img / 1e12, 2),
+                            "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},
+            "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
+            # the HBM-bandwidth-bound decoder head: low-res logits -> bilinear -> sigmoid/argmax -> 1 B/pixel
+            "roofline_hbm": {k: {"achieved_GBps": round(prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e9, 1),
+                                 "peak_GBps": 8000.0,
+                                 "frac": round(prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 8e12, 4),
+                                 "bytes_per_launch": prof[k]["work"] / max(prof[k]["launches"], 1)}
+                             for k in ("layernorm", "head1x1", "upsample") if prof[k]["ms"] > 0}}), flush=True)
+    barrier()
+
+
 def bench_train(args, cfg, model, x, rank, world, dev, barrier):
     """One step = LightningViTModel.training_step + backward + (N>1: RCCL all-reduce of the flat gradient
     arena) + Adam(lr=1e-5): BASELINE configs[2]/[3] (--precision bf16 = mixed precision, --batch 64)."""
@@ -172,13 +250,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 16 for l16_1024_tiled)")
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16", "f16"])
+    ap.add_argument("--workload", default="b16_512", choices=["b16_512", "l16_1024_tiled"],
+                    help="b16_512 = BASELINE configs[1] (default, the headline metric); l16_1024_tiled = configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode: dropout probability (reference 0.1)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="train: one step = forward + CE + backward + gradient all-reduce + Adam (fp32)")
     args = ap.parse_args()
+    tiled = args.workload == "l16_1024_tiled"
+    if args.precision is None:
+        args.precision = "f16" if tiled else "f32"
+    if args.batch is None:
+        args.batch = 16 if tiled else 32
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,20 +279,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if tiled:
+        return bench_tiled(args, rank, world, dev, barrier)
+
     cfg = vit_base16(num_classes=2, image_size=512)
     B = args.batch
     model = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
                                  cfg.num_attention_heads, image_size=cfg.image_size,
-                                 precision={"f32": "fp32", "bf16": "bf16"}[args.precision], dropout=args.dropout,
+                                 precision={"f32": "fp32", "bf16": "bf16", "f16": "fp16"}[args.precision], dropout=args.dropout,
                                  device=dev).eval()
     sd_np = synth.make_state_dict(cfg, seed=1)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     images_np = synth.make_images(cfg, B, seed=0, first_image=rank * B)  # this rank's shard of the image stream
     x = torch.from_numpy(images_np).to(dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
 
     if args.mode == "train":
         return bench_train(args, cfg, model, x, rank, world, dev, barrier)

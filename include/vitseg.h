@@ -87,7 +87,8 @@ enum vitseg_tensor {
 /* Precision of the encoder arithmetic. */
 enum vitseg_precision {
     VITSEG_F32 = 0, /* fp32 storage, fp32-input MFMA (exact fmaf chains): the parity path */
-    VITSEG_BF16 = 1 /* bf16 operands / fp32 accumulate MFMA, fp32 residual stream and softmax */
+    VITSEG_BF16 = 1, /* bf16 operands / fp32 accumulate MFMA, fp32 residual stream and softmax */
+    VITSEG_F16 = 2   /* IEEE-half operands, otherwise as VITSEG_BF16; inference only (BASELINE configs[4]) */
 };
 
 /* Workspace buffers whose contents are defined after vitseg_forward returns
@@ -107,6 +108,8 @@ int vitseg_param_offset(const vitseg_config* cfg, int tensor, int layer, size_t*
 
 /* fp32 arena -> bf16 shadow arena (same offsets, 2 bytes/elt); needed before a VITSEG_BF16 forward. */
 int vitseg_cast_params_bf16(const float* params, void* params_bf16, size_t n_floats, void* stream);
+/* same for IEEE half (VITSEG_F16); the shadow arena is passed in the params_bf16 slot of vitseg_forward */
+int vitseg_cast_params_f16(const float* params, void* params_f16, size_t n_floats, void* stream);
 
 /* ---- forward (replaces ViTSegmentationModel.forward, classes.py:246-262, and the
  *      sigmoid->argmax post-processing of testViTModel.py:122-126) ---- */
@@ -116,7 +119,7 @@ int vitseg_workspace_offset(const vitseg_config* cfg, int batch, int precision, 
 
 /* x: fp32 NCHW [batch, 3, S, S] on device.  logits (fp32 [batch, C, S, S]) and mask
  * (uint8 [batch, S, S], = argmax_c sigmoid(logits), first maximal index) may each be NULL.
- * params_bf16 is only read when precision == VITSEG_BF16. */
+ * params_bf16 (the 16-bit shadow arena in the format of `precision`) is only read when precision != VITSEG_F32. */
 int vitseg_forward(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x, int batch,
                    int precision, float* logits, uint8_t* mask, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -134,6 +137,10 @@ int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_pat
 int vitseg_op_linear_bf16(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N,
                           int K, int epilogue, void* stream);
 int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream);
+/* IEEE-half variants of the two above (operands as raw fp16 bits) */
+int vitseg_op_linear_f16(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K,
+                         int epilogue, void* stream);
+int vitseg_op_attention_f16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream);
 /* lowres fp32 [B, C, g, g] -> logits fp32 [B, C, S, S] and/or mask uint8 [B, S, S] */
 int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask, int batch, int C, int g, int S,
                               void* stream);

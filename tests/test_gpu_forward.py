@@ -86,22 +86,25 @@ def test_batch_invariance_and_determinism():
 
 # bf16 path: no hard gate from the reference (SURVEY 8d "parity gate"); the budget below is what bf16
 # operand rounding (2^-9 relative per tensor, 12 layers) gives on these O(0.1-1) logits.
+# IEEE half carries 3 more mantissa bits (2^-12): measured 2.7-4.7e-4, i.e. inside the fp32 path's 1e-3 gate.
 TOL_LOGITS_BF16 = 3e-2
+TOL_LOGITS_16 = {"bf16": TOL_LOGITS_BF16, "fp16": 1e-3}
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", [c for c in CASES if "sat" not in c])
-def test_forward_bf16_close_to_golden(name):
+def test_forward_bf16_close_to_golden(name, precision):
     g = Golden(name)
-    m = build(g, precision="bf16")
+    m = build(g, precision=precision)
     x = g.images().to(DEV)
     with torch.no_grad():
         mask, logits = m.predict_mask(x, return_logits=True)
     torch.cuda.synchronize()
     err, _ = g.max_abs_err("logits", logits)
-    assert err <= TOL_LOGITS_BF16, err
+    assert err <= TOL_LOGITS_16[precision], err
     ref = g.mask()
     mism = (mask.cpu().numpy() != ref).mean()
-    print(f"{name}: bf16 logits max-abs err {err:.3e}, mask mismatch rate {mism:.4%}")
+    print(f"{name}: {precision} logits max-abs err {err:.3e}, mask mismatch rate {mism:.4%}")
     assert mism < 0.05
 
 
@@ -132,14 +135,15 @@ def test_ce_loss_matches_reference(name):
     assert abs(float(got) - float(ref)) < 5e-6
 
 
-def test_vit_large_width_tiled_1024():
+@pytest.mark.parametrize("precision,margin", [("fp16", 4e-3), ("bf16", 2e-2)])
+def test_vit_large_width_tiled_1024(precision, margin):
     """BASELINE configs[4] shape family: ViT-L/16 width (D=1024, A=16; 2 layers here), 1024x1024 inputs as four
-    512x512 tiles through an image_size=512 model, bf16 operands (the build's half-precision path; fp16 is not
-    built).  Checked against the oracle run tile by tile."""
+    512x512 tiles through an image_size=512 model, fp16 operands as the config asks (and bf16).  Checked against
+    the oracle run tile by tile: every pixel whose top-2 logit margin exceeds the format's error must agree."""
     cfg = ViTSegConfig(2, 16, 1024, 2, 16, image_size=512)
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=51).items()}
     big = torch.from_numpy(synth.uniform01(9, "big", 3 * 1024 * 1024).reshape(1, 3, 1024, 1024).astype(np.float32))
-    m = ViTSegmentationModel(2, 16, 1024, 2, 16, image_size=512, precision="bf16", device=DEV).eval()
+    m = ViTSegmentationModel(2, 16, 1024, 2, 16, image_size=512, precision=precision, device=DEV).eval()
     m.load_state_dict(sd)
     mask = m.predict_mask_tiled(big.to(DEV)).cpu()
     assert mask.shape == (1, 1024, 1024)
@@ -149,7 +153,7 @@ def test_vit_large_width_tiled_1024():
                 tile = big[:, :, ty * 512:(ty + 1) * 512, tx * 512:(tx + 1) * 512]
                 ref = O.forward(tile, sd, cfg)
                 srt = ref.sort(dim=1, descending=True).values
-                solid = (srt[:, 0] - srt[:, 1]) > 2e-2  # bf16 logits are good to ~5e-3
+                solid = (srt[:, 0] - srt[:, 1]) > margin  # bf16 logits are good to ~5e-3, fp16 to ~1e-3
                 got = mask[:, ty * 512:(ty + 1) * 512, tx * 512:(tx + 1) * 512].long()
                 assert bool((got == O.predict_mask(ref))[solid].all())
     # fp32 path accepts the wide model too

@@ -125,43 +125,47 @@ def test_upsample_sigmoid_argmax_bit_exact(B, C, g, S):
     assert torch.equal(mask, mask2)
 
 
-# ---------------------------------------------------------------- bf16 kernels
-def _bf16_round(t):
-    return t.to(torch.bfloat16).float()
+# ---------------------------------------------------------------- 16-bit operand kernels (bf16 and IEEE half)
+FMT = {"bf16": (torch.bfloat16, 2 ** -8, "vitseg_op_linear_bf16", "vitseg_op_attention_bf16"),
+       "fp16": (torch.float16, 2 ** -11, "vitseg_op_linear_f16", "vitseg_op_attention_f16")}
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(128, 128, 64, 0), (257, 192, 128, 0), (788, 576, 192, 1), (1025, 768, 3072, 2),
                                        (2050, 2304, 768, 0), (33, 96, 64, 2), (130, 3072, 768, 1),
                                        (4129, 768, 768, 0), (4608, 384, 192, 1), (5000, 200, 3072, 2), (8224, 2304, 768, 0)])
-def test_linear_bf16(M, N, K, epi):
-    A, W = _bf16_round(_rand(M, K, seed=M)), _bf16_round(_rand(N, K, seed=N + 1, scale=0.05))
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+def test_linear_bf16(M, N, K, epi, fmt):
+    dt, ulp, fn, _ = FMT[fmt]
+    A, W = _rand(M, K, seed=M).to(dt).float(), _rand(N, K, seed=N + 1, scale=0.05).to(dt).float()
     bias, R = _rand(N, seed=7, scale=0.1), _rand(M, N, seed=11)
     acc = A.double() @ W.double().T + bias.double()  # exact products of bf16 values, fp32-accumulated on device
     ref = O.gelu_erf(acc) if epi == 1 else (R.double() + acc if epi == 2 else acc)
-    Ad, Wd = A.to(DEV).to(torch.bfloat16), W.to(DEV).to(torch.bfloat16)
+    Ad, Wd = A.to(DEV).to(dt), W.to(DEV).to(dt)
     bd, Rd = bias.to(DEV), R.to(DEV)
     if epi == 2:
         C = Rd.clone()
         Rp = C.data_ptr()
     else:
-        C = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        C = torch.zeros(M, N, device=DEV, dtype=dt)
         Rp = None
-    _lib.check(_lib.lib().vitseg_op_linear_bf16(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), Rp, C.data_ptr(), M, N, K,
-                                                epi, _stream()))
+    _lib.check(getattr(_lib.lib(), fn)(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), Rp, C.data_ptr(), M, N, K, epi,
+                                       _stream()))
     got = C.float().cpu().double()
     scale = (A.abs().double() @ W.abs().double().T).max().item()
     if epi == 2:   # fp32 output: only fp32 accumulation error
         assert (got - ref).abs().max().item() < 4e-7 * scale + 1e-5
-    else:          # bf16 output: one final rounding, 2^-9 relative
-        assert ((got - ref).abs() <= 2 ** -8 * ref.abs() + 4e-7 * scale + 1e-6).all()
+    else:          # 16-bit output: one final rounding (2^-9 relative for bf16, 2^-12 for half)
+        assert ((got - ref).abs() <= ulp * ref.abs() + 4e-7 * scale + 1e-6).all()
 
 
 @pytest.mark.parametrize("B,Np,A", [(2, 196, 3), (1, 1024, 2), (3, 784, 1), (1, 64, 1), (2, 128, 12), (1, 200, 2)])
-def test_attention_bf16(B, Np, A):
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+def test_attention_bf16(B, Np, A, fmt):
+    dt, ulp, _, fn = FMT[fmt]
     D = 64 * A
     Mt = B * Np + B
-    qkv = _bf16_round(_rand(Mt, 3 * D, seed=Np + A, scale=1.5))
-    qkv[Np // 2, :64] = _bf16_round(qkv[Np // 2, :64] * 6.0)
+    qkv = _rand(Mt, 3 * D, seed=Np + A, scale=1.5).to(dt).float()
+    qkv[Np // 2, :64] = (qkv[Np // 2, :64] * 6.0).to(dt).float()
     qkv[(Np * 3) // 4, D:D + 64] = qkv[Np // 2, :64]
     ref = torch.empty(Mt, D, dtype=torch.float64)
     x64 = qkv.double()
@@ -170,10 +174,10 @@ def test_attention_bf16(B, Np, A):
         q, k, v = [x64[r][:, i * D:(i + 1) * D].reshape(Np + 1, A, 64).transpose(0, 1) for i in range(3)]
         s = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
         ref[r] = (s @ v).transpose(0, 1).reshape(Np + 1, D)
-    qd = qkv.to(DEV).to(torch.bfloat16)
-    ctx = torch.zeros(Mt, D, device=DEV, dtype=torch.bfloat16)
-    _lib.check(_lib.lib().vitseg_op_attention_bf16(qd.data_ptr(), ctx.data_ptr(), B, Np, A, _stream()))
+    qd = qkv.to(DEV).to(dt)
+    ctx = torch.zeros(Mt, D, device=DEV, dtype=dt)
+    _lib.check(getattr(_lib.lib(), fn)(qd.data_ptr(), ctx.data_ptr(), B, Np, A, _stream()))
     err = (ctx.float().cpu().double() - ref).abs().max().item()
-    # P is rounded to bf16 (2^-9 relative) before P.V and the output is rounded to bf16: |v| <= ~6
-    assert err < 4e-2, err
-    assert (ctx.float().cpu().double() - ref).abs().mean().item() < 2e-3
+    # P is rounded to the operand format (2^-9 / 2^-12 relative) before P.V and the output is rounded too: |v| <= ~6
+    assert err < 4e-2 * ulp * 2 ** 8, err
+    assert (ctx.float().cpu().double() - ref).abs().mean().item() < 2e-3 * ulp * 2 ** 8

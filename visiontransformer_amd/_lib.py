@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvitseg.so")
 
 OK, EINVAL, ESHAPE, EWORKSPACE, EHIP = 0, -1, -2, -3, -4
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 BUF_TOKENS, BUF_LOWRES = 0, 1
 
 # enum vitseg_tensor
@@ -29,6 +29,7 @@ EXPORTS = [
     "vitseg_ce_scratch_bytes", "vitseg_ce_loss",
     "vitseg_train_workspace", "vitseg_forward_train", "vitseg_backward", "vitseg_adam_step",
     "vitseg_grad_bucket_count", "vitseg_grad_bucket_range",
+    "vitseg_cast_params_f16", "vitseg_op_linear_f16", "vitseg_op_attention_f16",
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
@@ -65,6 +66,7 @@ def lib() -> C.CDLL:
         l.vitseg_param_count.argtypes = [pcfg, psz]
         l.vitseg_param_offset.argtypes = [pcfg, i32, i32, psz, psz]
         l.vitseg_cast_params_bf16.argtypes = [vp, vp, sz, vp]
+        l.vitseg_cast_params_f16.argtypes = [vp, vp, sz, vp]
         l.vitseg_query_workspace.argtypes = [pcfg, i32, i32, psz]
         l.vitseg_workspace_offset.argtypes = [pcfg, i32, i32, i32, psz, psz]
         l.vitseg_forward.argtypes = [pcfg, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]
@@ -73,6 +75,8 @@ def lib() -> C.CDLL:
         l.vitseg_op_attention_f32.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_linear_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
+        l.vitseg_op_linear_f16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        l.vitseg_op_attention_f16.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_upsample_argmax.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_ce_scratch_bytes.argtypes = [i32, i32]
         l.vitseg_ce_scratch_bytes.restype = sz

@@ -23,21 +23,13 @@ constexpr int HD = 64;   // head dim
 constexpr int QB = 128;  // queries per block (4 waves x 32)
 constexpr int KB = 64;   // keys per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
-typedef unsigned short bf16_t;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    f32x2 f = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16v2));  // v_cvt_pk_bf16_f32
-}
-__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-
-template <bool RAGGED>
+// H: format tag of the 16-bit storage (bf16_t or f16_t, common.hpp H16<>); pointers are raw 16-bit words
+template <bool RAGGED, typename H>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ lse, int B, int Np, int A,
                                                            DropArgs dr) {
@@ -77,8 +69,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned qu = __float_as_uint(qf[s][e]), ku = __float_as_uint(kc[e]);
-                part = fmaf(bf_lo(qu), bf_lo(ku), part);
-                part = fmaf(bf_hi(qu), bf_hi(ku), part);
+                part = fmaf(H16<H>::lo(qu), H16<H>::lo(ku), part);
+                part = fmaf(H16<H>::hi(qu), H16<H>::hi(ku), part);
             }
         }
         m_run = part + __shfl_xor(part, 32, 64);
@@ -88,10 +80,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const uint2 t = *(const uint2*)(vbase + cls_row * ld + dt * 32 + 8 * g4 + 4 * lh);
-                o[dt][4 * g4 + 0] = bf_lo(t.x);
-                o[dt][4 * g4 + 1] = bf_hi(t.x);
-                o[dt][4 * g4 + 2] = bf_lo(t.y);
-                o[dt][4 * g4 + 3] = bf_hi(t.y);
+                o[dt][4 * g4 + 0] = H16<H>::lo(t.x);
+                o[dt][4 * g4 + 1] = H16<H>::hi(t.x);
+                o[dt][4 * g4 + 2] = H16<H>::lo(t.y);
+                o[dt][4 * g4 + 3] = H16<H>::hi(t.y);
             }
         if (dr.thresh) {
             const float kc = drop_keep(dkey, (unsigned)Np, dr.thresh) ? dr.scale : 0.f;
@@ -152,8 +144,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f32x4 kf = *(const f32x4*)&Ks[kb * 32 * HD + k_off + (((2 * s + lh) ^ k_sw) << 3)];
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                                 __builtin_bit_cast(bf16x8, qf[s]), st[kb], 0, 0, 0);
+                st[kb] = H16<H>::mfma(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), st[kb]);
             }
         }
         if (RAGGED) {
@@ -194,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
                     p0 = drop_keep(dkey, k0 + kappa(r, lh), dr.thresh) ? p0 * dr.scale : 0.f;
                     p1 = drop_keep(dkey, k0 + kappa(r + 1, lh), dr.thresh) ? p1 * dr.scale : 0.f;
                 }
-                pk[kb][r >> 1] = pack_bf16(p0, p1);
+                pk[kb][r >> 1] = H16<H>::pack2(p0, p1);
             }
         l_run += psum;
 
@@ -214,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(Vs + (row_a + 8) * HD + (ch << 3) + v_half));
                     const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                    o[dt] = H16<H>::mfma(vf, pf, o[dt]);
                 }
             }
 
@@ -235,14 +226,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 uint2 t;
-                t.x = pack_bf16(o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv);
-                t.y = pack_bf16(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+                t.x = H16<H>::pack2(o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv);
+                t.y = H16<H>::pack2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
                 *(uint2*)(out + dt * 32 + 8 * g4 + 4 * lh) = t;
             }
     }
 }
 
 // The B*A CLS queries: one block per (head, image); plain VALU in fp32 on bf16 inputs.
+template <typename H>
 __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                             float* __restrict__ lse, int B, int Np, int A,
                                                             DropArgs dr) {
@@ -261,7 +253,7 @@ __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __res
 
     const uint2 qu = *(const uint2*)(qp + 4 * sub);
     const float qs = 0.125f * LOG2E;
-    const float q0 = bf_lo(qu.x) * qs, q1 = bf_hi(qu.x) * qs, q2 = bf_lo(qu.y) * qs, q3 = bf_hi(qu.y) * qs;
+    const float q0 = H16<H>::lo(qu.x) * qs, q1 = H16<H>::hi(qu.x) * qs, q2 = H16<H>::lo(qu.y) * qs, q3 = H16<H>::hi(qu.y) * qs;
     // 4 keys per 16-lane group and iteration: four independent row loads in flight (the loop is latency-bound)
     for (int base = wave * 4; base < N; base += 256) {
         float part[4];
@@ -272,7 +264,7 @@ __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __res
             if (key < N) {
                 const size_t row = key < Np ? row0 + key : cls_row;
                 const uint2 ku = *(const uint2*)(kbase + row * ld + 4 * sub);
-                part[u] = q0 * bf_lo(ku.x) + q1 * bf_hi(ku.x) + q2 * bf_lo(ku.y) + q3 * bf_hi(ku.y);
+                part[u] = q0 * H16<H>::lo(ku.x) + q1 * H16<H>::hi(ku.x) + q2 * H16<H>::lo(ku.y) + q3 * H16<H>::hi(ku.y);
             }
         }
 #pragma unroll
@@ -326,10 +318,10 @@ __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __res
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            acc[0] = fmaf(pv[u], bf_lo(vu[u].x), acc[0]);
-            acc[1] = fmaf(pv[u], bf_hi(vu[u].x), acc[1]);
-            acc[2] = fmaf(pv[u], bf_lo(vu[u].y), acc[2]);
-            acc[3] = fmaf(pv[u], bf_hi(vu[u].y), acc[3]);
+            acc[0] = fmaf(pv[u], H16<H>::lo(vu[u].x), acc[0]);
+            acc[1] = fmaf(pv[u], H16<H>::hi(vu[u].x), acc[1]);
+            acc[2] = fmaf(pv[u], H16<H>::lo(vu[u].y), acc[2]);
+            acc[3] = fmaf(pv[u], H16<H>::hi(vu[u].y), acc[3]);
         }
     }
     *(f32x4*)&red[kg * 64 + 4 * sub] = acc;
@@ -337,28 +329,35 @@ __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __res
     if (tid < 64) {
         float s = 0.f;
         for (int gI = 0; gI < 64; ++gI) s += red[gI * 64 + tid];
-        ctx[cls_row * (size_t)D + head * HD + tid] = f32_to_bf16(s * inv);
+        ctx[cls_row * (size_t)D + head * HD + tid] = H16<H>::bits(s * inv);
     }
 }
 
 }  // namespace
 
-int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s) {
+template <typename H>
+static int launch_attention_h16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_bf16: bad arguments");
     const dim3 grid((unsigned)((Np + QB - 1) / QB) * A * B);  // 1-D: attn_tile() places the tiles
     if (Np % QB == 0)
-        hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B, Np,
-                           A, dr);
+        hipLaunchKernelGGL((attn_bf16_kernel<false, H>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B,
+                           Np, A, dr);
     else
-        hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B, Np,
-                           A, dr);
+        hipLaunchKernelGGL((attn_bf16_kernel<true, H>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B,
+                           Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_bf16");
     const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 64 * 64) * sizeof(float);
     VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_bf16: sequence too long for the CLS kernel");
-    hipLaunchKernelGGL(attn_cls_bf16_kernel, dim3(A, B), dim3(1024), smem, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B,
+    hipLaunchKernelGGL(attn_cls_bf16_kernel<H>, dim3(A, B), dim3(1024), smem, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B,
                        Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_cls_bf16");
     return VITSEG_OK;
+}
+
+int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s,
+                          bool f16) {
+    return f16 ? launch_attention_h16<f16_t>(qkv, ctx, lse, B, Np, A, dr, s)
+               : launch_attention_h16<bf16_t>(qkv, ctx, lse, B, Np, A, dr, s);
 }
 
 }  // namespace vitseg

@@ -138,4 +138,38 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
+// ---- the two 16-bit operand formats of the MFMA paths ----
+// bf16 (VITSEG_BF16: inference and mixed-precision training) is carried as raw bits; IEEE half (VITSEG_F16:
+// inference, BASELINE configs[4]) as _Float16 -- a distinct type, so one kernel template is instantiated per format
+// and H16<T> supplies the conversions and the 32x32x16 MFMA of that format.  Both round to nearest even.
+typedef unsigned short bf16_t;
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <typename H> struct H16;
+template <> struct H16<bf16_t> {
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi) { return pack2_bf16(lo, hi); }
+    static __device__ __forceinline__ unsigned short bits(float f) { return f32_to_bf16(f); }
+    static __device__ __forceinline__ float lo(unsigned u) { return __uint_as_float(u << 16); }
+    static __device__ __forceinline__ float hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+    static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct H16<f16_t> {
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+        f16x2 v = {(_Float16)lo, (_Float16)hi};
+        return __builtin_bit_cast(unsigned, v);
+    }
+    static __device__ __forceinline__ unsigned short bits(float f) {
+        return __builtin_bit_cast(unsigned short, (_Float16)f);
+    }
+    static __device__ __forceinline__ float lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+    static __device__ __forceinline__ float hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+    static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
+                                                      0, 0);
+    }
+};
+
 }  // namespace vitseg

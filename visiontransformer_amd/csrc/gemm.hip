@@ -31,8 +31,8 @@ constexpr int BKF = 32;    // row length in 4-byte LDS words
 
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int CE = 4, BKE = 32; };           // elements per chunk / per row
-template <> struct Elem<unsigned short> { static constexpr int CE = 8, BKE = 64; };  // bf16 bits
-typedef unsigned short bf16_t;
+template <> struct Elem<bf16_t> { static constexpr int CE = 8, BKE = 64; };          // bf16 bits
+template <> struct Elem<f16_t> { static constexpr int CE = 8, BKE = 64; };           // IEEE half
 
 template <typename T>
 struct ARow {
@@ -167,9 +167,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, a[slot][mi]), __builtin_bit_cast(bf16x8, b[slot][ni]),
-                            acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = H16<T>::mfma(__builtin_bit_cast(bf16x8, a[slot][mi]),
+                                                   __builtin_bit_cast(bf16x8, b[slot][ni]), acc[mi][ni]);
             }
         }
     };
@@ -383,9 +382,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                     extra[ps] = *(const f32x4*)(p.R + (size_t)grow * p.ldc + gcol);
                 if (EPI == EPI_DGELU && sizeof(T) == 2) {  // bf16 training: the saved pre-activation is bf16
                     const uint2 u = *(const uint2*)((const bf16_t*)p.R + (size_t)grow * p.ldc + gcol);
-                    extra[ps][0] = __uint_as_float(u.x << 16);
+                    extra[ps][0] = bf16_to_f32((unsigned short)u.x);
                     extra[ps][1] = __uint_as_float(u.x & 0xffff0000u);
-                    extra[ps][2] = __uint_as_float(u.y << 16);
+                    extra[ps][2] = bf16_to_f32((unsigned short)u.y);
                     extra[ps][3] = __uint_as_float(u.y & 0xffff0000u);
                 }
                 if (EPI == EPI_POS) extra[ps] = *(const f32x4*)(p.R + (size_t)(1 + grow % p.Np) * p.N + gcol);
@@ -414,17 +413,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                         *(f32x4*)((float*)p.aux + o) = aux4;
                     } else {
                         uint2 h;
-                        h.x = pack2_bf16(aux4[0], aux4[1]);
-                        h.y = pack2_bf16(aux4[2], aux4[3]);
-                        *(uint2*)((bf16_t*)p.aux + o) = h;
+                        h.x = H16<OutT>::pack2(aux4[0], aux4[1]);
+                        h.y = H16<OutT>::pack2(aux4[2], aux4[3]);
+                        *(uint2*)((OutT*)p.aux + o) = h;
                     }
                 }
                 if constexpr (sizeof(OutT) == 4) {
                     *(f32x4*)(C + o) = v[ps];
                 } else {
                     uint2 h;
-                    h.x = pack2_bf16(v[ps][0], v[ps][1]);
-                    h.y = pack2_bf16(v[ps][2], v[ps][3]);
+                    h.x = H16<OutT>::pack2(v[ps][0], v[ps][1]);
+                    h.y = H16<OutT>::pack2(v[ps][2], v[ps][3]);
                     *(uint2*)(C + o) = h;
                 }
             }
@@ -534,9 +533,8 @@ constexpr int LBM = 256;
 // LBN = 128: waves 4(M) x 2(N), 64x64 per wave, 3-stage ring (3 x 48 KiB), 85 FLOP per staged byte.
 // LBN = 256: waves 2(M) x 4(N), 128x64 per wave (128 accumulator registers), 2-stage ring (2 x 64 KiB),
 //            128 FLOP per staged byte -- half the L2->LDS traffic of the 128x128 kernel, which is what bounds it.
-template <typename OutT, int AMODE, int EPI, int LBN>
+template <typename T, typename OutT, int AMODE, int EPI, int LBN>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs p) {
-    typedef bf16_t T;
     constexpr int CE = 8, BKE = 64, BK = BKF;
     constexpr int STAGES = LBN == 128 ? 3 : 2;
     constexpr int MI = LBN == 128 ? 2 : 4, NI = 2;      // 32x32 MFMA tiles per wave
@@ -648,9 +646,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[slot][mi]),
-                                                                      __builtin_bit_cast(bf16x8, b[slot][ni]),
-                                                                      acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = H16<T>::mfma(__builtin_bit_cast(bf16x8, a[slot][mi]),
+                                           __builtin_bit_cast(bf16x8, b[slot][ni]), acc[mi][ni]);
     };
 
     const int KT = p.K / BKE;
@@ -754,8 +751,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
                         *(f32x4*)(C + o) = v[ps];
                     } else {
                         uint2 h;
-                        h.x = pack2_bf16(v[ps][0], v[ps][1]);
-                        h.y = pack2_bf16(v[ps][2], v[ps][3]);
+                        h.x = H16<OutT>::pack2(v[ps][0], v[ps][1]);
+                        h.y = H16<OutT>::pack2(v[ps][2], v[ps][3]);
                         *(uint2*)(C + o) = h;
                     }
                 }
@@ -765,7 +762,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
     }
 }
 
-template <typename OutT, int AMODE, int EPI, int LBN = 128>
+template <typename T, typename OutT, int AMODE, int EPI, int LBN = 128>
 int launch_large(GemmArgs a, hipStream_t s) {
     if (a.ldw == 0) a.ldw = a.K;
     if (!a.gn) a.gn = env_gn();
@@ -773,12 +770,12 @@ int launch_large(GemmArgs a, hipStream_t s) {
     const size_t smem = (size_t)(LBN == 128 ? 3 : 2) * (LBM + LBN) * BKF * sizeof(float);  // 144 / 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_large_kernel<OutT, AMODE, EPI, LBN>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_large)");
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_large_kernel<OutT, AMODE, EPI, LBN>), dim3(tiles), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN>), dim3(tiles), dim3(512), smem, s, a);
     VITSEG_LAUNCH_CHECK("gemm_bf16_large");
     return VITSEG_OK;
 }
@@ -841,7 +838,8 @@ int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, h
 
 // bf16 operands (A and W), fp32 accumulate.  Output type follows the consumer: bf16 for tensors
 // that feed the next MFMA (q|k|v, MLP hidden), fp32 for the residual stream and the head features.
-int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
+template <typename T>
+int launch_gemm_h16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, VITSEG_EINVAL, "gemm_bf16: bad M/N/K %d %d %d", a.M, a.N, a.K);
     VITSEG_CHECK_ARG(a.K % 64 == 0, VITSEG_ESHAPE, "gemm_bf16: K=%d must be a multiple of 64", a.K);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm: N=%d and ldc=%d must be multiples of 4", a.N,
@@ -854,22 +852,26 @@ int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 8 == 0, VITSEG_EINVAL, "gemm_bf16: lda %% 8");
         switch (epi) {
-            case EPI_BIAS: return xl ? launch_large<bf16_t, A_PLAIN, EPI_BIAS, 256>(a, s)
-                                  : large ? launch_large<bf16_t, A_PLAIN, EPI_BIAS>(a, s)
-                                          : launch_one<bf16_t, bf16_t, A_PLAIN, EPI_BIAS>(a, s);
-            case EPI_GELU: return xl ? launch_large<bf16_t, A_PLAIN, EPI_GELU, 256>(a, s)
-                                  : large ? launch_large<bf16_t, A_PLAIN, EPI_GELU>(a, s)
-                                          : launch_one<bf16_t, bf16_t, A_PLAIN, EPI_GELU>(a, s);
-            case EPI_RESADD: return xl ? launch_large<float, A_PLAIN, EPI_RESADD, 256>(a, s)
-                                    : large ? launch_large<float, A_PLAIN, EPI_RESADD>(a, s)
-                                            : launch_one<bf16_t, float, A_PLAIN, EPI_RESADD>(a, s);
+            case EPI_BIAS: return xl ? launch_large<T, T, A_PLAIN, EPI_BIAS, 256>(a, s)
+                                  : large ? launch_large<T, T, A_PLAIN, EPI_BIAS>(a, s)
+                                          : launch_one<T, T, A_PLAIN, EPI_BIAS>(a, s);
+            case EPI_GELU: return xl ? launch_large<T, T, A_PLAIN, EPI_GELU, 256>(a, s)
+                                  : large ? launch_large<T, T, A_PLAIN, EPI_GELU>(a, s)
+                                          : launch_one<T, T, A_PLAIN, EPI_GELU>(a, s);
+            case EPI_RESADD: return xl ? launch_large<T, float, A_PLAIN, EPI_RESADD, 256>(a, s)
+                                    : large ? launch_large<T, float, A_PLAIN, EPI_RESADD>(a, s)
+                                            : launch_one<T, float, A_PLAIN, EPI_RESADD>(a, s);
         }
     } else if (amode == A_CONV3 && epi == EPI_RELU) {
         VITSEG_CHECK_ARG(a.D % 64 == 0 && a.zeros, VITSEG_ESHAPE, "hidden size must be a multiple of 64");
-        return large ? launch_large<float, A_CONV3, EPI_RELU>(a, s) : launch_one<bf16_t, float, A_CONV3, EPI_RELU>(a, s);
+        return large ? launch_large<T, float, A_CONV3, EPI_RELU>(a, s) : launch_one<T, float, A_CONV3, EPI_RELU>(a, s);
     }
     set_error("gemm_bf16: unsupported amode/epilogue %d/%d", amode, epi);
     return VITSEG_EINVAL;
+}
+
+int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s, bool f16) {
+    return f16 ? launch_gemm_h16<f16_t>(a, amode, epi, s) : launch_gemm_h16<bf16_t>(a, amode, epi, s);
 }
 
 // =====================================================================================================

@@ -47,11 +47,12 @@ int launch_wgrad_f32(GemmArgs a, float* scratch, hipStream_t s);
 int launch_wgrad_bf16_tt(GemmArgs a, float* scratch, hipStream_t s);
 int launch_gemm_bf16_train(GemmArgs a, int epi, int out_f32, float* scratch, hipStream_t s);
 size_t wgrad_bf16_scratch_floats(int M, int N, int K);
-int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s);
+// 16-bit operands, fp32 accumulate; f16 selects IEEE half instead of bf16 (inference formats, common.hpp H16<>)
+int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s, bool f16 = false);
 
-// LayerNorm over the last dim (a4); out_bf16 selects the bf16-output variant.
+// LayerNorm over the last dim (a4); out_fmt: 0 fp32 output, 1 bf16, 2 IEEE half.
 int launch_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int D, float eps,
-                     bool out_bf16, hipStream_t s);
+                     int out_fmt, hipStream_t s);
 
 // Multi-head self-attention core (a6) on the patches-first row layout.
 // lse (optional): fp32 [B, A, Np+1] log2-domain log-sum-exp per query (CLS last), saved for the backward
@@ -59,7 +60,8 @@ int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np
 // dqkv[Mt,3D] from dctx[Mt,D]; dvec: scratch fp32 [B, A, Np+1]
 int launch_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dvec,
                              float* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s);
-int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s);
+int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s,
+                          bool f16 = false);
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dvec,
                               void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s);
 
@@ -76,7 +78,7 @@ int launch_ce_loss(const float* Z, const void* target, int target_is_u8, float* 
 // CLS token rows of the embedding output: X[B*Np + b] = cls + pos[0]  (a3)
 int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int Np, int D, hipStream_t s);
 
-int launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+int launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s, bool f16 = false);
 // dropout on a row-major [rows][cols] fp32 tensor: dst = keep ? src * scale : 0 (dst may alias src; dst_bf16 selects
 // a bf16 destination).  Used for the embedding dropout and for masking branch gradients in the backward.
 int launch_dropout_rows(const float* src, void* dst, int dst_bf16, int rows, int cols, DropArgs d, hipStream_t s);

@@ -57,10 +57,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if constexpr (sizeof(OutT) == 4) {
                 ((f32x4*)(y + (size_t)row * D))[c] = o;
             } else {
-                bf16x4 h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (short)f32_to_bf16(o[e]);
-                ((bf16x4*)(y + (size_t)row * D))[c] = h;
+                uint2 h;
+                h.x = H16<OutT>::pack2(o[0], o[1]);
+                h.y = H16<OutT>::pack2(o[2], o[3]);
+                ((uint2*)(y + (size_t)row * D))[c] = h;
             }
         }
     }
@@ -76,15 +76,16 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
     X[((size_t)B * Np + b) * D + d] = cls[d] + pos[d];
 }
 
-__global__ void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n4) {
+template <typename H>
+__global__ void cast_bf16_kernel(const float* __restrict__ src, H* __restrict__ dst, size_t n4) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
         const f32x4 v = ((const f32x4*)src)[i];
-        bf16x4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (short)f32_to_bf16(v[e]);
-        ((bf16x4*)dst)[i] = h;
+        uint2 h;
+        h.x = H16<H>::pack2(v[0], v[1]);
+        h.y = H16<H>::pack2(v[2], v[3]);
+        ((uint2*)dst)[i] = h;
     }
 }
 
@@ -125,16 +126,19 @@ int launch_dropout_rows(const float* src, void* dst, int dst_bf16, int rows, int
 }
 
 int launch_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int D, float eps,
-                     bool out_bf16, hipStream_t s) {
+                     int out_fmt, hipStream_t s) {
     VITSEG_CHECK_ARG(x && w && b && y && rows > 0, VITSEG_EINVAL, "layernorm: bad arguments");
     VITSEG_CHECK_ARG(D % 4 == 0 && D <= 2048, VITSEG_ESHAPE, "layernorm: D=%d must be a multiple of 4 and <= 2048", D);
     const dim3 grid((rows + 3) / 4);
     const int nvl = (D / 4 + 63) / 64;  // vectors per lane
 #define VITSEG_LN(NV)                                                                                              \
     do {                                                                                                           \
-        if (out_bf16)                                                                                              \
-            hipLaunchKernelGGL((layernorm_kernel<unsigned short, NV>), grid, dim3(256), 0, s, x, w, b,            \
-                               (unsigned short*)y, rows, D, eps);                                                  \
+        if (out_fmt == 1)                                                                                          \
+            hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), grid, dim3(256), 0, s, x, w, b, (bf16_t*)y, rows, D, \
+                               eps);                                                                               \
+        else if (out_fmt == 2)                                                                                     \
+            hipLaunchKernelGGL((layernorm_kernel<f16_t, NV>), grid, dim3(256), 0, s, x, w, b, (f16_t*)y, rows, D,  \
+                               eps);                                                                               \
         else                                                                                                       \
             hipLaunchKernelGGL((layernorm_kernel<float, NV>), grid, dim3(256), 0, s, x, w, b, (float*)y, rows, D,  \
                                eps);                                                                               \
@@ -155,11 +159,14 @@ int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int Np,
     return VITSEG_OK;
 }
 
-int launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
+int launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s, bool f16) {
     VITSEG_CHECK_ARG(n % 4 == 0, VITSEG_EINVAL, "cast_bf16: n %% 4");
     const size_t n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, s, src, (unsigned short*)dst, n4);
+    if (f16)
+        hipLaunchKernelGGL(cast_bf16_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, src, (f16_t*)dst, n4);
+    else
+        hipLaunchKernelGGL(cast_bf16_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, src, (bf16_t*)dst, n4);
     VITSEG_LAUNCH_CHECK("cast_bf16");
     return VITSEG_OK;
 }

@@ -39,7 +39,7 @@ Plan make_plan(const Shape& s, int B, int precision) {
     Plan p{};
     p.Mp = (size_t)B * s.Np;
     p.Mt = p.Mp + B;
-    const size_t act = precision == VITSEG_BF16 ? 2 : 4;
+    const size_t act = precision == VITSEG_F32 ? 4 : 2;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t o = off;
@@ -140,11 +140,16 @@ int vitseg_cast_params_bf16(const float* params, void* params_bf16, size_t n_flo
     return launch_cast_bf16(params, params_bf16, n_floats, (hipStream_t)stream);
 }
 
+int vitseg_cast_params_f16(const float* params, void* params_f16, size_t n_floats, void* stream) {
+    VITSEG_CHECK_ARG(params && params_f16, VITSEG_EINVAL, "null arena");
+    return launch_cast_bf16(params, params_f16, n_floats, (hipStream_t)stream, true);
+}
+
 int vitseg_query_workspace(const vitseg_config* cfg, int batch, int precision, size_t* bytes) {
     Shape s;
     if (int rc = check_config(cfg, &s)) return rc;
     VITSEG_CHECK_ARG(batch >= 1 && bytes, VITSEG_EINVAL, "batch %d / null out pointer", batch);
-    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL, "precision %d", precision);
+    VITSEG_CHECK_ARG(precision >= VITSEG_F32 && precision <= VITSEG_F16, VITSEG_EINVAL, "precision %d", precision);
     *bytes = make_plan(s, batch, precision).total;
     return VITSEG_OK;
 }
@@ -173,11 +178,11 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     if (int rc = check_config(cfg, &s)) return rc;
     VITSEG_CHECK_ARG(params && x && workspace && batch >= 1, VITSEG_EINVAL, "null pointer or batch < 1");
     VITSEG_CHECK_ARG(logits || mask, VITSEG_EINVAL, "both outputs are null");
-    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL, "precision %d", precision);
-    VITSEG_CHECK_ARG(precision == VITSEG_F32 || params_bf16, VITSEG_EINVAL, "bf16 forward needs the bf16 arena");
+    VITSEG_CHECK_ARG(precision >= VITSEG_F32 && precision <= VITSEG_F16, VITSEG_EINVAL, "precision %d", precision);
+    VITSEG_CHECK_ARG(precision == VITSEG_F32 || params_bf16, VITSEG_EINVAL, "16-bit forward needs the 16-bit arena");
     VITSEG_CHECK_ARG(((uintptr_t)params | (uintptr_t)x | (uintptr_t)workspace | (uintptr_t)logits) % 16 == 0,
                      VITSEG_EINVAL, "pointers must be 16-byte aligned");
-    const bool lp = precision == VITSEG_BF16;
+    const bool lp = precision != VITSEG_F32, f16 = precision == VITSEG_F16;
     const Plan p = make_plan(s, batch, precision);
     VITSEG_CHECK_ARG(workspace_bytes >= p.total, VITSEG_EWORKSPACE, "workspace %zu < required %zu", workspace_bytes,
                      p.total);
@@ -215,11 +220,11 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     const double ln_bytes = 2.0 * Mt * D * 4;
     auto gemm = [&](const GemmArgs& g, int epi, int kind) {
         ProfScope ps(kind, 2.0 * g.M * g.N * g.K, st);
-        return lp ? launch_gemm_bf16(g, A_PLAIN, epi, st) : launch_gemm_f32(g, A_PLAIN, epi, st);
+        return lp ? launch_gemm_bf16(g, A_PLAIN, epi, st, f16) : launch_gemm_f32(g, A_PLAIN, epi, st);
     };
     auto lnorm = [&](const float* w, const float* b, int rows) {
         ProfScope ps(VITSEG_K_LAYERNORM, (double)rows * D * (lp ? 6 : 8), st);
-        return launch_layernorm(X, w, b, H, rows, D, cfg->layer_norm_eps, lp, st);
+        return launch_layernorm(X, w, b, H, rows, D, cfg->layer_norm_eps, lp ? (f16 ? 2 : 1) : 0, st);
     };
     (void)ln_bytes;
     for (int l = 0; l < s.L; ++l) {
@@ -230,7 +235,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         if ((rc = gemm(g, EPI_BIAS, VITSEG_K_GEMM_BIAS))) return rc;
         {
             ProfScope ps(VITSEG_K_ATTENTION, 4.0 * batch * s.A * (double)s.N * s.N * 64, st);
-            rc = lp ? launch_attention_bf16(QKV, H, nullptr, batch, s.Np, s.A, DropArgs{}, st)
+            rc = lp ? launch_attention_bf16(QKV, H, nullptr, batch, s.Np, s.A, DropArgs{}, st, f16)
                     : launch_attention_f32((const float*)QKV, (float*)H, nullptr, batch, s.Np, s.A, DropArgs{}, st);
             if (rc) return rc;
         }
@@ -263,7 +268,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         }
         {
             ProfScope ps(VITSEG_K_GEMM_CONV3, 2.0 * g.M * g.N * g.K, st);
-            rc = lp ? launch_gemm_bf16(g, A_CONV3, EPI_RELU, st) : launch_gemm_f32(g, A_CONV3, EPI_RELU, st);
+            rc = lp ? launch_gemm_bf16(g, A_CONV3, EPI_RELU, st, f16) : launch_gemm_f32(g, A_CONV3, EPI_RELU, st);
             if (rc) return rc;
         }
         ProfScope ps(VITSEG_K_HEAD1X1, (double)Mp * MID * 4 + (double)batch * s.C * s.Np * 4, st);
@@ -340,6 +345,17 @@ int vitseg_op_linear_bf16(const void* A, const void* Wt, const float* bias, cons
     return launch_gemm_bf16(g, A_PLAIN, epilogue, (hipStream_t)stream);
 }
 
+int vitseg_op_linear_f16(const void* A, const void* Wt, const float* bias, const float* R, void* C, int M, int N, int K,
+                         int epilogue, void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "linear: null pointer");
+    VITSEG_CHECK_ARG(epilogue >= 0 && epilogue <= 2, VITSEG_EINVAL, "linear_f16: epilogue %d", epilogue);
+    VITSEG_CHECK_ARG(epilogue != EPI_RESADD || R, VITSEG_EINVAL, "linear: residual epilogue needs R");
+    GemmArgs g{};
+    g.A = A; g.W = Wt; g.bias = bias; g.R = R; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
+    return launch_gemm_bf16(g, A_PLAIN, epilogue, (hipStream_t)stream, true);
+}
+
 int vitseg_op_gemm_f32(const float* A, const float* Wt, const float* R, float* C, int M, int N, int K, int ta, int tb,
                        int epilogue, void* stream) {
     VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "gemm: null pointer");
@@ -366,6 +382,11 @@ int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, 
 
 int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream) {
     return launch_attention_bf16(qkv, ctx, nullptr, batch, num_patches, num_heads, DropArgs{}, (hipStream_t)stream);
+}
+
+int vitseg_op_attention_f16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream) {
+    return launch_attention_bf16(qkv, ctx, nullptr, batch, num_patches, num_heads, DropArgs{}, (hipStream_t)stream,
+                                 true);
 }
 
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {

@@ -150,7 +150,8 @@ struct Ctx {
 int init_ctx(Ctx& c, const vitseg_config* cfg, const float* params, int B, int precision, void* ws, size_t ws_bytes,
              void* stream) {
     if (int rc = check_config(cfg, &c.s)) return rc;
-    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL, "precision %d", precision);
+    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL,
+                     "training runs in VITSEG_F32 or VITSEG_BF16 (precision %d; fp16 is an inference format)", precision);
     VITSEG_CHECK_ARG(params && ws && B >= 1, VITSEG_EINVAL, "null pointer or batch < 1");
     VITSEG_CHECK_ARG(c.s.C <= 32, VITSEG_ESHAPE, "training supports at most 32 classes (got %d)", c.s.C);
     c.p = make_train_plan(c.s, B, precision);
@@ -360,7 +361,8 @@ int vitseg_train_workspace(const vitseg_config* cfg, int batch, int precision, s
     Shape s;
     if (int rc = check_config(cfg, &s)) return rc;
     VITSEG_CHECK_ARG(batch >= 1 && bytes, VITSEG_EINVAL, "batch %d / null out pointer", batch);
-    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL, "precision %d", precision);
+    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_BF16, VITSEG_EINVAL,
+                     "training runs in VITSEG_F32 or VITSEG_BF16 (precision %d; fp16 is an inference format)", precision);
     *bytes = make_train_plan(s, batch, precision).total;
     return VITSEG_OK;
 }

@@ -18,7 +18,8 @@ import torch.nn as nn
 from . import _lib, params as _params
 from .config import ViTSegConfig
 
-_PRECISION = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.BF16, "bfloat16": _lib.BF16}
+_PRECISION = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.BF16, "bfloat16": _lib.BF16,
+              "fp16": _lib.F16, "f16": _lib.F16, "float16": _lib.F16, "half": _lib.F16}
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -176,15 +177,19 @@ class ViTSegmentationModel(nn.Module):
         return ws
 
     def _bf16_arena(self):
-        if self.precision != _lib.BF16:
+        """16-bit shadow of the arena in the format of `self.precision` (bf16 or IEEE half), refreshed when the
+        fp32 master changes."""
+        if self.precision == _lib.F32:
             return None
         ver = (self.arena._version, self.arena.data_ptr())
         if self._arena_bf16 is None or self._bf16_version != ver:
+            f16 = self.precision == _lib.F16
             if self._arena_bf16 is None:
-                self._arena_bf16 = torch.empty(self.arena.numel(), dtype=torch.bfloat16, device=self.arena.device)
-            _lib.check(_lib.lib().vitseg_cast_params_bf16(self.arena.data_ptr(), self._arena_bf16.data_ptr(),
-                                                          self.arena.numel(),
-                                                          torch.cuda.current_stream().cuda_stream))
+                self._arena_bf16 = torch.empty(self.arena.numel(), dtype=torch.float16 if f16 else torch.bfloat16,
+                                               device=self.arena.device)
+            cast = _lib.lib().vitseg_cast_params_f16 if f16 else _lib.lib().vitseg_cast_params_bf16
+            _lib.check(cast(self.arena.data_ptr(), self._arena_bf16.data_ptr(), self.arena.numel(),
+                            torch.cuda.current_stream().cuda_stream))
             self._bf16_version = ver
         return self._arena_bf16
 
