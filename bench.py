@@ -192,6 +192,94 @@ def bench_tiled(args, rank, world, dev, barrier):
     barrier()
 
 
+def bench_aux(args, rank, world, dev, barrier):
+    """Rows f3 / f4 of SURVEY.md section 8 to the same bar as the hot path: --mode prep = Resize((512, 512)) + ToTensor
+    of 3024x4032 RGB photos (uint8 in HBM -> fp32 NCHW), --mode eval = per-image class statistics of 512x512
+    predictions against 256x256 label maps.  HBM-bound byte work: roofline = algorithmic bytes / hipEvent time."""
+    from visiontransformer_amd.metrics import Evaluator
+    from visiontransformer_amd.preprocess import Preprocessor
+    B, S = args.batch, 512
+    rs = np.random.RandomState(rank)
+    if args.mode == "prep":
+        H, W = 3024, 4032
+        host = rs.randint(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+        src = torch.from_numpy(host).to(dev)
+        pre = Preprocessor(S, dev)
+        out = torch.empty((B, 3, S, S), dtype=torch.float32, device=dev)
+        run = lambda: pre.images(src, out)
+        yb = pre._axis_tables(H, S)
+        rows = yb[4] - yb[3]
+        # read the photo once, write + re-read the uint8 intermediate, write the fp32 tensor
+        algo = B * (H * W * 3 + 2 * rows * S * 3 + 3 * S * S * 4)
+        what = f"Resize(({S},{S})) + ToTensor of {B} RGB photos {H}x{W} per GPU (uint8 resident in HBM)"
+    else:
+        pred = torch.from_numpy(rs.randint(0, 17, size=(B, S, S), dtype=np.uint8)).to(dev)
+        gt = torch.from_numpy(rs.randint(0, 17, size=(B, 256, 256), dtype=np.uint8)).to(dev)
+        ev = Evaluator(17, dev)
+        run = lambda: ev.counts(pred, gt)
+        algo = B * (S * S + 256 * 256 + 3 * 256 * 8)
+        what = f"class statistics (accuracy/IoU/Dice inputs) of {B} predictions {S}x{S} vs 256x256 labels per GPU"
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        res = run()
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / args.steps     # kernels are launched on torch's current stream
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        out_json = {
+            "metric": "images/sec pre-processed" if args.mode == "prep" else "images/sec evaluated",
+            "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": what, "batch_per_gpu": B, "parallelism": f"batch-split x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(algo / (dev_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(algo / (dev_ms * 1e-3) / 8e12, 4), "traffic": None,
+                         "kernel": "resize_h_kernel + resize_v_tensor_kernel" if args.mode == "prep" else "eval_counts_kernel",
+                         "device_ms_per_step": round(dev_ms, 4), "algorithmic_bytes_per_step": algo}}
+        if not args.no_cpu_baseline:
+            if args.mode == "prep":   # what the reference's DataLoader workers run per image: Pillow resize + /255
+                from PIL import Image
+                n, t1 = 0, time.perf_counter()
+                while time.perf_counter() - t1 < 10.0:
+                    im = Image.fromarray(host[n % B], "RGB").resize((S, S), Image.BILINEAR)
+                    ref = torch.from_numpy(np.asarray(im)).permute(2, 0, 1).contiguous().float().div(255)
+                    n += 1
+                dt = time.perf_counter() - t1
+                ok = bool(torch.equal(ref, res[(n - 1) % B].cpu()))
+                out_json["cpu_baseline"] = {"value": round(n / dt, 2), "unit": "images/s", "cores": 1, "kind": "reference",
+                                            "sample": f"Pillow {Image.__version__} Image.resize(BILINEAR) + ToTensor on {n} of the "
+                                                      f"same photos, one host thread (the reference uses 2 DataLoader workers)"}
+                out_json["parity"] = {"bit_exact_vs_pillow": ok}
+            else:
+                from oracle import preproc_oracle as O
+                n, t1 = 0, time.perf_counter()
+                p_np, g_np = pred.cpu().numpy(), gt.cpu().numpy()
+                while time.perf_counter() - t1 < 10.0:
+                    ref = O.image_metrics(p_np[n % B], g_np[n % B], 17)
+                    n += 1
+                dt = time.perf_counter() - t1
+                from visiontransformer_amd.metrics import metrics_from_counts
+                got = metrics_from_counts(res[(n - 1) % B].cpu().numpy(), 17, S * S)
+                out_json["cpu_baseline"] = {"value": round(n / dt, 2), "unit": "images/s", "cores": 1, "kind": "port",
+                                            "sample": f"oracle restatement of datasetTestViTmodel.py:193-219 (numpy) on {n} of the same pairs"}
+                out_json["parity"] = {"metrics_identical": bool(all(got[k] == ref[k] for k in ("Accuracy", "Mean_IoU", "Mean_Dice")))}
+        print(json.dumps(out_json), flush=True)
+    barrier()
+
+
 def bench_train(args, cfg, model, x, rank, world, dev, barrier):
     """One step = LightningViTModel.training_step + backward + (N>1: RCCL all-reduce of the flat gradient
     arena) + Adam(lr=1e-5): BASELINE configs[2]/[3] (--precision bf16 = mixed precision, --batch 64)."""
@@ -256,7 +344,7 @@ def main():
                     help="b16_512 = BASELINE configs[1] (default, the headline metric); l16_1024_tiled = configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode: dropout probability (reference 0.1)")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "prep", "eval"],
                     help="train: one step = forward + CE + backward + gradient all-reduce + Adam (fp32)")
     args = ap.parse_args()
     tiled = args.workload == "l16_1024_tiled"
@@ -285,6 +373,8 @@ def main():
 
     if tiled:
         return bench_tiled(args, rank, world, dev, barrier)
+    if args.mode in ("prep", "eval"):
+        return bench_aux(args, rank, world, dev, barrier)
 
     cfg = vit_base16(num_classes=2, image_size=512)
     B = args.batch

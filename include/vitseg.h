@@ -184,6 +184,36 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const void* p
  * reduce that range while the rest of the backward still runs. */
 int vitseg_grad_bucket_count(const vitseg_config* cfg);
 int vitseg_grad_bucket_range(const vitseg_config* cfg, int bucket, size_t* offset_floats, size_t* n_floats);
+/* ---- pre-processing (replaces transforms.Resize((S, S)) + transforms.ToTensor() on the PIL image,
+ *      trainCurrentViTmodel.py:48-51 / testViTModel.py:92-97, and the mask side Resize(NEAREST) + value->class
+ *      remap + F.interpolate(nearest), classes.py:76-83, 273-274).  Bit-exact with Pillow's 8-bit two-pass
+ *      antialiased bilinear resampling (libImaging/Resample.c) and with its NEAREST (Geometry.c).
+ * Host side (no GPU touched): vitseg_resize_taps = taps per output sample of one axis; vitseg_resize_coeffs fills
+ * bounds[out][2] = (first source index, tap count) and kk[out][taps] (22-bit fixed point) for that axis;
+ * vitseg_nearest_index fills the source index of every destination sample (mode 0 = Image.resize(NEAREST),
+ * 1 = F.interpolate(mode='nearest')).  The caller uploads the tables once per (source size, S).
+ * Device side: vitseg_preprocess_u8 turns n RGB images uint8 [n, H, W, 3] into fp32 [n, 3, S, S] in [0, 1];
+ * x* tables (and scratch >= n * rows * S * 3 bytes) are needed when W != S, y* tables when H != S;
+ * [row_first, row_first + rows) = the source rows the vertical pass touches (ybounds[0][0] .. last bound).
+ * vitseg_resize_nearest_u8 gathers uint8 [n, H, W] -> [n, out_h, out_w] through the index tables and an optional
+ * 256-entry LUT, writing uint8 or int64 (torch.long targets). */
+int vitseg_resize_taps(int in_size, int out_size);
+int vitseg_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk);
+int vitseg_nearest_index(int in_size, int out_size, int mode, int32_t* idx);
+int vitseg_preprocess_u8(const uint8_t* img, int n, int H, int W, int S, const int32_t* xbounds, const int32_t* xk, int xksize,
+                         const int32_t* ybounds, const int32_t* yk, int yksize, int row_first, int rows, uint8_t* scratch,
+                         float* out, void* stream);
+int vitseg_resize_nearest_u8(const uint8_t* src, int n, int H, int W, const int32_t* yidx, const int32_t* xidx, int out_h,
+                             int out_w, const uint8_t* lut, int out_is_i64, void* out, void* stream);
+
+/* ---- evaluation statistics (replaces the per-image numpy loops of datasetTestViTmodel.py:193-219) ----
+ * pred: uint8 [n, S, S] class masks; gt: uint8 [n, gt_h, gt_w] label maps, nearest-resized on the fly through
+ * yidx/xidx (device tables of S entries each; NULL when the sizes already match).  counts: int64 [n, 3, 256] =
+ * per label value |gt == v & pred == v|, |gt == v|, |pred == v|; accuracy, IoU, Dice and the class sets follow from
+ * these integers exactly. */
+int vitseg_eval_counts(const uint8_t* pred, const uint8_t* gt, int n, int S, int gt_h, int gt_w, const int32_t* yidx,
+                       const int32_t* xidx, int64_t* counts, void* stream);
+
 /* one Adam step over a flat fp32 buffer (torch.optim.Adam semantics, weight_decay 0, amsgrad off);
  * step is 1-based; gradients are multiplied by grad_scale first (1/world for summed all-reduce). */
 int vitseg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n_floats, float lr,

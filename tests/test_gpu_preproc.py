@@ -1,0 +1,119 @@
+"""GPU (-m gpu): device pre-processing (f3) and evaluation counting (f4) through the C ABI, bit-exact against the oracle
+and the Pillow / torch fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import make_golden_preproc as G
+from oracle import preproc_oracle as O
+from visiontransformer_amd.metrics import Evaluator
+from visiontransformer_amd.preprocess import NEAREST_PIL, NEAREST_TORCH, Preprocessor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "preproc", "preproc.npz"))
+
+
+@pytest.mark.parametrize("seed,H,W,S", G.RESIZE_CASES)
+def test_resize_to_tensor_matches_pillow_fixture(seed, H, W, S):
+    a = G.image(seed, H, W)
+    x = Preprocessor(S, DEV).images(torch.from_numpy(a))
+    assert x.shape == (1, 3, S, S) and x.dtype == torch.float32
+    assert np.array_equal(x[0].cpu().numpy(), O.to_tensor(Z[f"resize.{seed}.out"]))   # bit-exact, /255 included
+
+
+def test_resize_batch_ragged_and_large():
+    rs = np.random.RandomState(3)
+    pre = Preprocessor(224, DEV)
+    batch = rs.randint(0, 256, size=(3, 150, 310, 3), dtype=np.uint8)       # a batch of equal-size frames
+    x = pre.images(torch.from_numpy(batch)).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(x[i], O.preprocess_image(batch[i], 224))
+    for H, W in [(224, 300), (300, 224), (224, 224), (1, 1), (2, 999), (1536, 2048)]:   # one axis equal, identity, tiny, photo
+        a = rs.randint(0, 256, size=(H, W, 3), dtype=np.uint8)
+        assert np.array_equal(pre.images(torch.from_numpy(a))[0].cpu().numpy(), O.preprocess_image(a, 224)), (H, W)
+    with pytest.raises(ValueError):
+        pre.images(torch.zeros(4, 4, 4, dtype=torch.uint8))
+
+
+@pytest.mark.parametrize("seed,H,W,oh,ow,C", G.NEAREST_CASES)
+def test_mask_resize_and_remap(seed, H, W, oh, ow, C):
+    m = G.nearest_source(seed, H, W)
+    pre = Preprocessor(224, DEV)
+    got = pre.masks(torch.from_numpy(m), (oh, ow), NEAREST_PIL, dtype=torch.uint8)[0].cpu().numpy()
+    assert np.array_equal(got, Z[f"nearest.{seed}.pil"])
+    got = pre.masks(torch.from_numpy(m), (oh, ow), NEAREST_TORCH, dtype=torch.uint8)[0].cpu().numpy()
+    assert np.array_equal(got, Z[f"nearest.{seed}.torch"])
+    mapping = {int(v): int(v) * 7 % C for v in np.unique(m)}
+    y = pre.masks(torch.from_numpy(m), (oh, ow), NEAREST_PIL, value_to_class=mapping)     # torch.long, as the dataset yields
+    assert y.dtype == torch.long
+    lut = np.zeros(256, np.uint8)
+    for v, c in mapping.items():
+        lut[v] = c
+    assert np.array_equal(y[0].cpu().numpy(), lut[Z[f"nearest.{seed}.pil"]].astype(np.int64))
+
+
+@pytest.mark.parametrize("seed,gs,ps,C", G.METRIC_CASES)
+def test_eval_counts_and_metrics(seed, gs, ps, C):
+    gt, pred = G.metric_pair(seed, gs, ps, C, lambda g: O.resize_nearest_lut(g, ps, ps, "pil"))
+    ev = Evaluator(C, DEV)
+    # a batch of two: the case and a shifted copy (different statistics per image)
+    pred2 = np.roll(pred, 17, axis=1)
+    counts = ev.counts(torch.from_numpy(np.stack([pred, pred2])), torch.from_numpy(np.stack([gt, gt]))).cpu().numpy()
+    gt_r = O.resize_nearest_lut(gt, ps, ps, "pil")
+    assert np.array_equal(counts[0], O.class_counts(pred, gt_r, 256))
+    assert np.array_equal(counts[1], O.class_counts(pred2, gt_r, 256))
+    m = ev.evaluate(torch.from_numpy(pred[None]), torch.from_numpy(gt[None]))[0]
+    exp = Z[f"metric.{seed}.scalars"]
+    assert np.array_equal(np.array([m["Accuracy"], m["Mean_IoU"], m["Mean_Dice"]]), exp, equal_nan=True)
+    ref = O.image_metrics(pred, gt, C)
+    for k in ("GT_Classes", "Pred_Classes", "Missing_Classes", "False_Positive_Classes"):
+        assert m[k] == ref[k]
+
+
+def test_eval_counts_full_size_properties():
+    """BASELINE batch size (32 x 512 x 512): conservation laws of the counts -- every pixel is counted once per side,
+    agreement never exceeds either side, identical inputs give 100 % -- and labels outside the class range (255 =
+    ignore) are kept in the class sets exactly as np.unique would."""
+    rs = np.random.RandomState(0)
+    pred = torch.from_numpy(rs.randint(0, 17, size=(32, 512, 512), dtype=np.uint8))
+    gt = torch.from_numpy(rs.randint(0, 17, size=(32, 256, 256), dtype=np.uint8))
+    gt[:, :8] = 255
+    ev = Evaluator(17, DEV)
+    c = ev.counts(pred, gt).cpu().numpy()
+    assert (c[:, 1].sum(1) == 512 * 512).all() and (c[:, 2].sum(1) == 512 * 512).all()
+    assert (c[:, 0] <= c[:, 1]).all() and (c[:, 0] <= c[:, 2]).all()
+    assert (c[:, 1, 255] > 0).all() and 255 in ev.evaluate(pred[:1], gt[:1])[0]["GT_Classes"]
+    same = ev.evaluate(pred, pred)
+    assert all(m["Accuracy"] == 100.0 and m["Mean_IoU"] == 1.0 and m["Mean_Dice"] == 1.0 for m in same)
+    i = 5
+    ref = O.image_metrics(pred[i].numpy(), gt[i].numpy(), 17)
+    got = ev.evaluate(pred[i:i + 1], gt[i:i + 1])[0]
+    assert got["Accuracy"] == ref["Accuracy"] and got["Mean_IoU"] == ref["Mean_IoU"] and got["Mean_Dice"] == ref["Mean_Dice"]
+
+
+def test_predict_from_encoded_bytes_uses_device_preprocessing():
+    """predict(): PNG bytes -> decode (host) -> Resize + ToTensor (device) -> model -> mask; equals the oracle's
+    pre-processing followed by the same model, and the mask of a second call is identical (cached tables)."""
+    import io
+    from PIL import Image
+    from visiontransformer_amd import synth
+    from visiontransformer_amd.config import ViTSegConfig
+    from visiontransformer_amd.model import ViTSegmentationModel
+    from visiontransformer_amd.predict import predict
+    cfg = ViTSegConfig(3, 16, 192, 2, 3, image_size=224)
+    m = ViTSegmentationModel(3, 16, 192, 2, 3, image_size=224, device=DEV).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=5).items()})
+    a = np.random.RandomState(11).randint(0, 256, size=(333, 500, 3), dtype=np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(a, "RGB").save(buf, format="PNG")
+    colors = np.array([[0, 0, 0], [255, 0, 0], [0, 255, 0]], np.uint8)
+    mask, rgb, logits = predict(buf.getvalue(), m, index_to_color=colors, return_logits=True)
+    x = torch.from_numpy(O.preprocess_image(a, 224))[None].to(DEV)
+    with torch.no_grad():
+        ref_mask, ref_logits = m.predict_mask(x, return_logits=True)
+    assert np.array_equal(mask, ref_mask[0].cpu().numpy()) and np.array_equal(logits, ref_logits[0].cpu().numpy())
+    assert rgb.shape == (224, 224, 3) and np.array_equal(rgb, colors[mask])
+    assert np.array_equal(predict(a, m), mask)

@@ -38,17 +38,30 @@ def load_model(model_id_or_config, num_classes: int, checkpoint: Optional[str] =
     return model.eval()
 
 
-def preprocess(image, size: int) -> torch.Tensor:
-    """PIL image / path / encoded bytes -> float32 [1, 3, size, size] in [0, 1]
-    (= transforms.Resize((S, S)) [bilinear, antialiased] + ToTensor, testViTModel.py:92-97)."""
+def decode(image) -> np.ndarray:
+    """PIL image / path / encoded bytes -> uint8 RGB [H, W, 3] (`Image.open(...).convert('RGB')`, classes.py:72)."""
     from PIL import Image
     if isinstance(image, (bytes, bytearray)):
         image = Image.open(io.BytesIO(image))
     elif isinstance(image, (str, os.PathLike)):
         image = Image.open(image)
-    image = image.convert("RGB").resize((size, size), Image.BILINEAR)
-    arr = np.asarray(image, dtype=np.float32) / 255.0
-    return torch.from_numpy(arr).permute(2, 0, 1).unsqueeze(0).contiguous()
+    if isinstance(image, np.ndarray):
+        return np.ascontiguousarray(image, dtype=np.uint8)
+    return np.asarray(image.convert("RGB"), dtype=np.uint8)
+
+
+_PRE = {}
+
+
+def preprocess(image, size: int, device="cuda:0") -> torch.Tensor:
+    """image -> float32 [1, 3, size, size] in [0, 1] on `device`: transforms.Resize((S, S)) [Pillow's antialiased
+    bilinear] + ToTensor (testViTModel.py:92-97), computed by libvitseg bit-exactly (preprocess.Preprocessor); only the
+    decoded bytes are uploaded."""
+    from .preprocess import Preprocessor
+    key = (int(size), str(device))
+    if key not in _PRE:
+        _PRE[key] = Preprocessor(size, device)
+    return _PRE[key].images(torch.from_numpy(decode(image)))
 
 
 def predict(image, model: Union[LightningViTModel, ViTSegmentationModel], *, index_to_color=None,
@@ -56,7 +69,7 @@ def predict(image, model: Union[LightningViTModel, ViTSegmentationModel], *, ind
     """uint8 class-index mask [S, S] (numpy) for one image; optionally also an RGB rendering
     `index_to_color[mask]` (testViTModel.py:139-143) and/or the fp32 logits [C, S, S]."""
     seg = model.model if isinstance(model, LightningViTModel) else model
-    x = preprocess(image, seg.cfg.image_size).to(seg.arena.device)
+    x = preprocess(image, seg.cfg.image_size, seg.arena.device)
     out = seg.predict_mask(x, return_logits=return_logits)
     mask = (out[0] if return_logits else out)[0].cpu().numpy()
     res = [mask]
