@@ -117,3 +117,47 @@ def test_predict_from_encoded_bytes_uses_device_preprocessing():
     assert np.array_equal(mask, ref_mask[0].cpu().numpy()) and np.array_equal(logits, ref_logits[0].cpu().numpy())
     assert rgb.shape == (224, 224, 3) and np.array_equal(rgb, colors[mask])
     assert np.array_equal(predict(a, m), mask)
+
+
+def test_worker_end_to_end_on_the_gpu():
+    """Row f2 with the real network behind it: images of different sizes are queued over HTTP, batched into one forward
+    on the MI355X and come back as colourised PNGs equal to predict() on each image alone."""
+    import io
+    import threading
+    import time
+    from PIL import Image
+    from test_worker_cpu import TOKEN, FakeBackend, _png, _post
+    from visiontransformer_amd import synth
+    from visiontransformer_amd.config import ViTSegConfig
+    from visiontransformer_amd.predict import predict
+    from visiontransformer_amd.worker import Worker, gpu_slot
+    slot = gpu_slot((16, 192, 2, 3), 3, image_size=224, device=DEV)
+    cfg = ViTSegConfig(3, 16, 192, 2, 3, image_size=224)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=5).items()}
+    from visiontransformer_amd.model import ViTSegmentationModel
+    ref_model = ViTSegmentationModel(3, 16, 192, 2, 3, image_size=224, device=DEV).eval()
+    ref_model.load_state_dict(sd)
+    slot.model.model.load_state_dict(sd)   # same weights as the stand-alone model (gpu_slot starts from random init)
+    be = FakeBackend()
+    w = Worker({1: slot}, be.url, TOKEN, max_batch=8, batch_wait_s=0.05)
+    srv = w.serve("127.0.0.1", 0)
+    threading.Thread(target=srv.serve_forever, daemon=True).start()
+    url = f"http://127.0.0.1:{srv.server_address[1]}"
+    rs = np.random.RandomState(4)
+    imgs = [rs.randint(0, 256, size=(h, wd, 3), dtype=np.uint8) for h, wd in [(224, 224), (100, 333), (480, 640), (50, 50), (224, 300)]]
+    try:
+        for i, a in enumerate(imgs):
+            assert _post(url + "/enqueue/", {"job_id": f"j{i}", "vision_model_id": "1"},
+                         {"input_image": ("x.png", _png(a), "image/png")})[0] == 202
+        for _ in range(500):
+            if len(be.done) == len(imgs):
+                break
+            time.sleep(0.02)
+        assert len(be.done) == len(imgs) and w.stats["failed"] == 0
+        for i, a in enumerate(imgs):
+            got = np.array(Image.open(io.BytesIO(be.done[f"j{i}"][1])).convert("RGB"))
+            assert np.array_equal(got, slot.palette[predict(a, ref_model)])
+    finally:
+        srv.shutdown()
+        w.stop()
+        be.srv.shutdown()

@@ -47,7 +47,7 @@ def decode(image) -> np.ndarray:
         image = Image.open(image)
     if isinstance(image, np.ndarray):
         return np.ascontiguousarray(image, dtype=np.uint8)
-    return np.asarray(image.convert("RGB"), dtype=np.uint8)
+    return np.array(image.convert("RGB"), dtype=np.uint8)   # a writable copy (torch.from_numpy wants one)
 
 
 _PRE = {}
