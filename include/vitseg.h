@@ -206,6 +206,15 @@ int vitseg_preprocess_u8(const uint8_t* img, int n, int H, int W, int S, const i
 int vitseg_resize_nearest_u8(const uint8_t* src, int n, int H, int W, const int32_t* yidx, const int32_t* xidx, int out_h,
                              int out_w, const uint8_t* lut, int out_is_i64, void* out, void* stream);
 
+/* ---- soft PAED loss for C classes (replaces softmax + one_hot + paed_loss_multiclass_soft and its autograd in the
+ *      17-class LightningViTModel of model/PAED, classes.py:336-369, 449-478).  logits: fp32 [B, C, H, W]; target:
+ *      class indices [B, H, W] (int64 or uint8); sigma = 3 and class_penalty = 1 are the reference's defaults.  Writes
+ *      the scalar loss and, when grad_logits != NULL, d loss / d logits (fp32 [B, C, H, W]).  scratch:
+ *      vitseg_paed_scratch_bytes() device bytes. */
+size_t vitseg_paed_scratch_bytes(int batch, int C, int H, int W);
+int vitseg_paed_multiclass_loss(const float* logits, const void* target, int target_is_u8, int batch, int C, int H, int W,
+                                float sigma, int class_penalty, void* scratch, float* loss, float* grad_logits, void* stream);
+
 /* ---- evaluation statistics (replaces the per-image numpy loops of datasetTestViTmodel.py:193-219) ----
  * pred: uint8 [n, S, S] class masks; gt: uint8 [n, gt_h, gt_w] label maps, nearest-resized on the fly through
  * yidx/xidx (device tables of S entries each; NULL when the sizes already match).  counts: int64 [n, 3, 256] =

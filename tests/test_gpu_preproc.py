@@ -161,3 +161,55 @@ def test_worker_end_to_end_on_the_gpu():
         srv.shutdown()
         w.stop()
         be.srv.shutdown()
+
+
+# ---------------------------------------------------------------- row f1: soft PAED loss for C classes, fused
+def test_paed_multiclass_fused_matches_reference_golden():
+    """csrc/paed_loss.hip against values and gradients produced by the REAL paed_loss_multiclass_soft
+    (tests/golden/paed/paed_losses.npz, oracle/make_golden_paed.py)."""
+    from oracle.make_golden_paed import paed_inputs
+    from visiontransformer_amd import paed
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "paed", "paed_losses.npz"))
+    logits, y, *_ = paed_inputs()
+    lg = logits.to(DEV).requires_grad_(True)
+    loss = paed.paed_multiclass_loss_fused(lg, y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(G["multiclass.loss"][0])) < 2e-7 * max(1.0, abs(float(G["multiclass.loss"][0])))
+    ref = G["multiclass.grad"]
+    assert np.abs(lg.grad.cpu().numpy() - ref).max() < 2e-6 * np.abs(ref).max() + 1e-12
+
+
+@pytest.mark.parametrize("B,C,H,W,sigma,pen,u8", [(2, 17, 224, 224, 3, True, False), (1, 5, 50, 70, 3, True, True),
+                                                  (3, 4, 33, 21, 2, False, False), (1, 2, 8, 8, 3, True, True)])
+def test_paed_multiclass_fused_matches_torch_autograd(B, C, H, W, sigma, pen, u8):
+    """Shapes the golden file does not hold (non-square, maps smaller than the 19-tap window, class_penalty off,
+    uint8 targets) against fp64 autograd through the plain-torch restatement of the reference function."""
+    import torch.nn.functional as F
+    from visiontransformer_amd import paed
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    logits = torch.randn(B, C, H, W, generator=g) * 2
+    y = torch.randint(0, C, (B, H, W), generator=g)
+    ld = logits.double().requires_grad_(True)
+    # as the reference: the Gaussian is built in fp32; everything downstream in fp64 here
+    k = int(6 * sigma + 1)
+    ax = torch.arange(k, dtype=torch.float32) - k // 2
+    g1 = torch.exp(-(ax ** 2) / (2 * sigma ** 2))
+    g2 = (g1[:, None] * g1[None, :])
+    g2 = (g2 / g2.sum()).double()[None, None].repeat(C, 1, 1, 1)
+    p = torch.softmax(ld, dim=1)
+    t = F.one_hot(y, C).permute(0, 3, 1, 2).double()
+    diff = (F.conv2d(t, g2, padding=k // 2, groups=C) - F.conv2d(p, g2, padding=k // 2, groups=C)).abs()
+    if pen:
+        diff = t * (1 - p) * diff * 2
+    ref = diff.mean(dim=[2, 3]).mean(dim=1).mean()
+    ref.backward()
+    lg = logits.to(DEV).requires_grad_(True)
+    yt = (y.to(torch.uint8) if u8 else y).to(DEV)
+    loss = paed.paed_multiclass_loss_fused(lg, yt, sigma=sigma, class_penalty=pen)
+    (loss * 3.0).backward()                      # the upstream gradient scales it
+    assert abs(loss.item() - ref.item()) < 3e-6 * max(1.0, abs(ref.item()))
+    gr = ld.grad.numpy() * 3.0
+    assert np.abs(lg.grad.cpu().numpy() - gr).max() < 1e-5 * np.abs(gr).max() + 1e-12
+    with torch.no_grad():                        # no gradient requested: loss only
+        assert abs(paed.paed_multiclass_loss_fused(logits.to(DEV), yt, sigma=sigma, class_penalty=pen).item() - ref.item()) \
+            < 3e-6 * max(1.0, abs(ref.item()))

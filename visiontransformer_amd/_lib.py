@@ -31,7 +31,7 @@ EXPORTS = [
     "vitseg_grad_bucket_count", "vitseg_grad_bucket_range",
     "vitseg_cast_params_f16", "vitseg_op_linear_f16", "vitseg_op_attention_f16",
     "vitseg_resize_taps", "vitseg_resize_coeffs", "vitseg_nearest_index", "vitseg_preprocess_u8",
-    "vitseg_resize_nearest_u8", "vitseg_eval_counts",
+    "vitseg_resize_nearest_u8", "vitseg_eval_counts", "vitseg_paed_scratch_bytes", "vitseg_paed_multiclass_loss",
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
@@ -89,6 +89,9 @@ def lib() -> C.CDLL:
         l.vitseg_backward.argtypes = [pcfg, vp, vp, vp, i32, i32, f32, C.c_uint64, vp, i32, vp, vp, vp, vp, vp, sz, vp]
         l.vitseg_grad_bucket_count.argtypes = [pcfg]
         l.vitseg_resize_taps.argtypes = [i32, i32]
+        l.vitseg_paed_scratch_bytes.argtypes = [i32, i32, i32, i32]
+        l.vitseg_paed_scratch_bytes.restype = sz
+        l.vitseg_paed_multiclass_loss.argtypes = [vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp]
         l.vitseg_resize_coeffs.argtypes = [i32, i32, vp, vp]
         l.vitseg_nearest_index.argtypes = [i32, i32, i32, vp]
         l.vitseg_preprocess_u8.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]

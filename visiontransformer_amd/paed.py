@@ -1,10 +1,12 @@
 """PAED entry points of the reference (model/PAED/classes.py) on the MI355X model.
 
 `ViTSegmentationModel` is the same class as in model/CE (the reference keeps a byte-identical copy at
-model/PAED/classes.py:372-413); what differs is the loss tail.  The tails are elementwise / small-stencil
-maths on the logits and run as PyTorch-ROCm tensor ops here ("keep as
-PyTorch-ROCm ops initially"); their gradient reaches the parameters through libvitseg's backward
-(`vitseg_backward` with `grad_logits`).  Lightning's logging is replaced by a `logged` dict.
+model/PAED/classes.py:372-413); what differs is the loss tail.  The 17-class soft
+PAED loss and its gradient are libvitseg kernels (`paed_multiclass_loss_fused`, csrc/paed_loss.hip); the binary
+trainer's BCE + Dice + Sobel/SDF tail is elementwise / small-stencil maths that still runs as PyTorch-ROCm tensor
+ops on the logits.  Either way the gradient reaches the parameters through libvitseg's backward (`vitseg_backward`
+with `grad_logits`).  Lightning's logging is replaced by a `logged` dict.  The plain-torch functions below
+(`paed_loss_multiclass_soft`, ...) mirror the reference's free functions of the same names.
 
   * `LightningViTModel` -- 17-class soft-PAED loss, Adam(lr=1e-4)          (model/PAED/classes.py:415-487)
   * `PAEDTrainer`       -- binary BCE + 0.1 Dice + 5 |soft-PAED|, AdamW(1e-4) + ReduceLROnPlateau (:490-701)
@@ -35,6 +37,45 @@ def paed_loss_multiclass_soft(msk, pred_mask, num_classes=17, sigma=3, class_pen
     if class_penalty:
         diff = msk * (1 - pred_mask) * diff * 2
     return diff.mean(dim=[2, 3]).mean(dim=1).mean()
+
+
+class _PAEDMulticlassFn(torch.autograd.Function):
+    """softmax + one_hot + paed_loss_multiclass_soft and its gradient as libvitseg kernels (csrc/paed_loss.hip):
+    one call yields the loss and d loss / d logits, the backward only scales it."""
+
+    @staticmethod
+    def forward(ctx, logits, target, sigma, class_penalty):
+        from . import _lib
+        logits = logits.contiguous().float()
+        target = target.contiguous()
+        if target.dtype not in (torch.int64, torch.uint8):
+            raise ValueError(f"target must be int64 or uint8 class indices, got {target.dtype}")
+        B, Cc, H, W = logits.shape
+        if tuple(target.shape) != (B, H, W):
+            raise ValueError(f"target shape {tuple(target.shape)} does not match logits {tuple(logits.shape)}")
+        need_grad = logits.requires_grad
+        L = _lib.lib()
+        scratch = torch.empty(L.vitseg_paed_scratch_bytes(B, Cc, H, W), dtype=torch.uint8, device=logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        grad = torch.empty_like(logits) if need_grad else None
+        with torch.cuda.device(logits.device):
+            _lib.check(L.vitseg_paed_multiclass_loss(
+                logits.data_ptr(), target.data_ptr(), int(target.dtype == torch.uint8), B, Cc, H, W, float(sigma),
+                int(bool(class_penalty)), scratch.data_ptr(), loss.data_ptr(), None if grad is None else grad.data_ptr(),
+                torch.cuda.current_stream().cuda_stream))
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ctx.grad * grad_out, None, None, None
+
+
+def paed_multiclass_loss_fused(logits, target, sigma=3, class_penalty=True):
+    """`paed_loss_multiclass_soft(one_hot(target), softmax(logits, 1), sigma=sigma, class_penalty=...)`
+    (model/PAED/classes.py:336-369, called at :455-462) computed on the device in one fused call; differentiable w.r.t.
+    `logits` [B, C, H, W].  `target`: class indices [B, H, W], int64 or uint8."""
+    return _PAEDMulticlassFn.apply(logits, target, sigma, class_penalty)
 
 
 def dice_loss(preds, targets, smooth=1e-6):
@@ -104,11 +145,11 @@ class LightningViTModel(_Base):
     def _step(self, batch, tag):
         x, y = batch
         y = self._resize_target(y)
-        probs = torch.softmax(self.forward(x), dim=1)
-        onehot = F.one_hot(y, self.num_classes).permute(0, 3, 1, 2).float()
-        loss = paed_loss_multiclass_soft(onehot, probs, num_classes=self.num_classes)
+        logits = self.forward(x)
+        # softmax + one-hot + blur + weighting and their gradient run in libvitseg (csrc/paed_loss.hip)
+        loss = paed_multiclass_loss_fused(logits, y)
         self.logged[f"{tag}_loss"] = float(loss.detach())
-        self.logged[f"{tag}_iou"] = float(iou_score(probs.argmax(dim=1), y, self.num_classes))
+        self.logged[f"{tag}_iou"] = float(iou_score(logits.detach().argmax(dim=1), y, self.num_classes))  # argmax(softmax) = argmax
         return loss
 
     def training_step(self, batch, batch_idx):
