@@ -34,25 +34,29 @@ from visiontransformer_amd import _lib, synth  # noqa: E402
 from visiontransformer_amd.config import vit_base16  # noqa: E402
 from visiontransformer_amd.model import ViTSegmentationModel  # noqa: E402
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f32x3": 2500.0 / 3}  # x3: 3 fp16 MFMAs per product  # dense MFMA peaks, MI355X_MICROARCH.md
 KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
-    "f32": {"gemm_bias": "gemm_kernel<float, float, 0, 0, 0, 0>", "gemm_gelu": "gemm_kernel<float, float, 0, 1, 0, 0>",
-            "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0>",
-            "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0>",
+    "f32": {"gemm_bias": "gemm_kernel<float, float, 0, 0, 0, 0, 0>", "gemm_gelu": "gemm_kernel<float, float, 0, 1, 0, 0, 0>",
+            "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0, 0>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
+            "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 0>",
             "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
     "bf16": {"gemm_bias": "gemm_bf16_large_kernel<unsigned short, unsigned short, 0, 0, 256>",
              "gemm_gelu": "gemm_bf16_large_kernel<unsigned short, unsigned short, 0, 1, 256>",
-             "gemm_resadd": "gemm_kernel<unsigned short, float, 0, 2, 0, 0> (o_proj) + "
+             "gemm_resadd": "gemm_kernel<unsigned short, float, 0, 2, 0, 0, 0> (o_proj) + "
                             "gemm_bf16_large_kernel<unsigned short, float, 0, 2, 128> (fc2)",
-             "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0>",
+             "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
              "gemm_conv3": "gemm_bf16_large_kernel<unsigned short, float, 2, 3, 128>",
              "attention": "attn_bf16_kernel<false, unsigned short> + attn_cls_bf16_kernel<unsigned short>"},
+    "f32x3": {"gemm_bias": "gemm_kernel<float, float, 0, 0, 0, 0, 1>", "gemm_gelu": "gemm_kernel<float, float, 0, 1, 0, 0, 1>",
+              "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0, 1>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 1>",
+              "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 1>",
+              "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
     # rocprofv3's demangler does not know _Float16 (DF16_): the IEEE-half instantiations appear mangled in its CSVs
     "f16": {"gemm_bias": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_DF16_Li0ELi0ELi256EEEvNS_8GemmArgsE",
             "gemm_gelu": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_DF16_Li0ELi1ELi256EEEvNS_8GemmArgsE",
-            "gemm_resadd": "_ZN6vitseg12_GLOBAL__N_111gemm_kernelIDF16_fLi0ELi2ELi0ELi0EEEvNS_8GemmArgsE (o_proj) + "
+            "gemm_resadd": "_ZN6vitseg12_GLOBAL__N_111gemm_kernelIDF16_fLi0ELi2ELi0ELi0ELi0EEEvNS_8GemmArgsE (o_proj) + "
                            "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi0ELi2ELi128EEEvNS_8GemmArgsE (fc2)",
-            "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0>",
+            "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
             "gemm_conv3": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi2ELi3ELi128EEEvNS_8GemmArgsE",
             "attention": "_ZN6vitseg12_GLOBAL__N_116attn_bf16_kernelILb0EDF16_EEvPKtPtPfiiiNS_8DropArgsE + "
                          "_ZN6vitseg12_GLOBAL__N_120attn_cls_bf16_kernelIDF16_EEvPKtPtPfiiiNS_8DropArgsE"},
@@ -110,17 +114,22 @@ def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.
             mask = O.predict_mask(O.forward(x, sd, cfg))
             times.append(time.perf_counter() - t0)
     t = float(np.median(times)) if times else first
+    base = {"value": n / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (pure-torch restatement of model/CE forward + sigmoid/argmax), fp32, "
+                      f"{n} x {cfg.image_size}x{cfg.image_size} images, median of {max(len(times), 1)} runs"}
+    return base, parity_vs(gpu_logits, gpu_mask, logits, mask), (logits, mask)
+
+
+def parity_vs(gpu_logits, gpu_mask, logits, mask):
+    """GPU output of the first images against oracle logits / mask of the same images."""
+    n = logits.shape[0]
     err = float((gpu_logits[:n].cpu() - logits).abs().max())
     srt = logits.sort(dim=1, descending=True).values
     solid = (srt[:, 0] - srt[:, 1]) > 1e-4
     match_all = float((gpu_mask[:n].cpu().long() == mask).float().mean())
     match_solid = float((gpu_mask[:n].cpu().long() == mask)[solid].float().mean())
-    base = {"value": n / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (pure-torch restatement of model/CE forward + sigmoid/argmax), fp32, "
-                      f"{n} x {cfg.image_size}x{cfg.image_size} images, median of {max(len(times), 1)} runs"}
-    parity = {"logits_max_abs_err": err, "mask_match": match_all, "mask_match_margin_gt_1e-4": match_solid,
-              "images_checked": n}
-    return base, parity
+    return {"logits_max_abs_err": err, "mask_match": match_all, "mask_match_margin_gt_1e-4": match_solid,
+            "images_checked": n}
 
 
 def bench_tiled(args, rank, world, dev, barrier):
@@ -339,7 +348,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 16 for l16_1024_tiled)")
-    ap.add_argument("--precision", default=None, choices=["f32", "bf16", "f16"])
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16", "f16", "f32x3"])
     ap.add_argument("--workload", default="b16_512", choices=["b16_512", "l16_1024_tiled"],
                     help="b16_512 = BASELINE configs[1] (default, the headline metric); l16_1024_tiled = configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -380,7 +389,7 @@ def main():
     B = args.batch
     model = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
                                  cfg.num_attention_heads, image_size=cfg.image_size,
-                                 precision={"f32": "fp32", "bf16": "bf16", "f16": "fp16"}[args.precision], dropout=args.dropout,
+                                 precision={"f32": "fp32", "bf16": "bf16", "f16": "fp16", "f32x3": "fp32x3"}[args.precision], dropout=args.dropout,
                                  device=dev).eval()
     sd_np = synth.make_state_dict(cfg, seed=1)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
@@ -451,28 +460,35 @@ def main():
                              for k in ("layernorm", "upsample") if prof[k]["ms"] > 0},
         }
         if args.precision == "f32" and not args.no_cpu_baseline:
-            # informational: the same step on the bf16-operand path (outside the timed region, rank 0 only)
-            m16 = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
-                                       cfg.num_attention_heads, image_size=cfg.image_size, precision="bf16",
-                                       device=dev).eval()
-            m16.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
-            with torch.no_grad():
-                for _ in range(3):
-                    mk16, lg16 = m16.predict_mask(x, return_logits=True)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(10):
-                    mk16, lg16 = m16.predict_mask(x, return_logits=True)
-                torch.cuda.synchronize()
-                dt16 = (time.perf_counter() - t1) / 10
-            out["bf16_path"] = {"images_per_s_per_gpu": round(B / dt16, 1), "ms_per_step": round(dt16 * 1e3, 3),
-                                "logits_max_abs_diff_vs_f32": float((lg16 - logits).abs().max()),
-                                "mask_agreement_vs_f32": float((mk16 == mask).float().mean())}
-            del m16
+            # informational (outside the timed region, rank 0 only): the same step on the other operand formats.
+            # f32x3 = fp32 storage, GEMM operands split into half pairs, 3 fp16 MFMAs per product (fp32-grade results);
+            # bf16 = bf16 operands / fp32 accumulate.  The timed `value` above is the exact-fp32 MFMA path.
+            for prec, key in (("fp32x3", "f32x3_path"), ("bf16", "bf16_path")):
+                m2 = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+                                          cfg.num_attention_heads, image_size=cfg.image_size, precision=prec,
+                                          device=dev).eval()
+                m2.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+                with torch.no_grad():
+                    for _ in range(3):
+                        mk2, lg2 = m2.predict_mask(x, return_logits=True)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(10):
+                        mk2, lg2 = m2.predict_mask(x, return_logits=True)
+                    torch.cuda.synchronize()
+                    dt2 = (time.perf_counter() - t1) / 10
+                out[key] = {"images_per_s_per_gpu": round(B / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3),
+                            "logits_max_abs_diff_vs_f32": float((lg2 - logits).abs().max()),
+                            "mask_agreement_vs_f32": float((mk2 == mask).float().mean())}
+                if prec == "fp32x3":
+                    lg_x3, mk_x3 = lg2, mk2
+                del m2
         if not args.no_cpu_baseline:
-            base, parity = cpu_baseline(cfg, sd_np, images_np, logits, mask)
+            base, parity, oracle_out = cpu_baseline(cfg, sd_np, images_np, logits, mask)
             out["cpu_baseline"] = base
             out["parity"] = parity
+            if args.precision == "f32":   # the split-operand path against the same oracle run
+                out["f32x3_path"]["parity_vs_oracle"] = parity_vs(lg_x3, mk_x3, *oracle_out)
         print(json.dumps(out), flush=True)
     barrier()
     if world > 1:

@@ -88,7 +88,10 @@ enum vitseg_tensor {
 enum vitseg_precision {
     VITSEG_F32 = 0, /* fp32 storage, fp32-input MFMA (exact fmaf chains): the parity path */
     VITSEG_BF16 = 1, /* bf16 operands / fp32 accumulate MFMA, fp32 residual stream and softmax */
-    VITSEG_F16 = 2   /* IEEE-half operands, otherwise as VITSEG_BF16; inference only (BASELINE configs[4]) */
+    VITSEG_F16 = 2,  /* IEEE-half operands, otherwise as VITSEG_BF16; inference only (BASELINE configs[4]) */
+    VITSEG_F32X3 = 3 /* fp32 storage everywhere; GEMM operands split into (hi, lo) half pairs while staged and multiplied
+                        with 3 fp16 MFMAs per product (22-bit operand significands, fp32 accumulate); attention,
+                        LayerNorm, softmax as VITSEG_F32.  Inference only. */
 };
 
 /* Workspace buffers whose contents are defined after vitseg_forward returns
@@ -137,6 +140,9 @@ int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_pat
 int vitseg_op_linear_bf16(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N,
                           int K, int epilogue, void* stream);
 int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream);
+/* fp32 in / fp32 out through the split-operand fp16 MFMA path of VITSEG_F32X3 (same arguments as linear_f32) */
+int vitseg_op_linear_f32x3(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
+                           int K, int epilogue, void* stream);
 /* IEEE-half variants of the two above (operands as raw fp16 bits) */
 int vitseg_op_linear_f16(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K,
                          int epilogue, void* stream);

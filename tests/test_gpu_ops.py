@@ -181,3 +181,30 @@ def test_attention_bf16(B, Np, A, fmt):
     # P is rounded to the operand format (2^-9 / 2^-12 relative) before P.V and the output is rounded too: |v| <= ~6
     assert err < 4e-2 * ulp * 2 ** 8, err
     assert (ctx.float().cpu().double() - ref).abs().mean().item() < 2e-3 * ulp * 2 ** 8
+
+
+# ---------------------------------------------------------------- fp32 operands on the fp16 pipe (VITSEG_F32X3)
+@pytest.mark.parametrize("M,N,K,epi", [(128, 128, 64, 0), (257, 192, 96, 0), (788, 576, 192, 1), (1025, 768, 3072, 2),
+                                       (2050, 2304, 768, 0), (33, 96, 32, 2), (130, 3072, 768, 1)])
+def test_linear_f32x3_is_fp32_grade(M, N, K, epi):
+    """Split-operand GEMM: a = hi + lo * 2^-11 in half precision, 3 MFMAs per product.  Each product is good to
+    ~2^-21 relative (lo.lo' dropped, low parts rounded), so the result must sit within 1e-6 of the fp64 value relative
+    to sum |a||w| -- the same budget class as true fp32 accumulation (4e-7), far from half precision (5e-4)."""
+    A, W = _rand(M, K, seed=M), _rand(N, K, seed=N + 1, scale=0.05)
+    A[0, :4] = torch.tensor([1e-6, -3e-5, 2.5e3, -7.0])        # tiny, subnormal-half and large magnitudes in one row
+    bias, R = _rand(N, seed=7, scale=0.1), _rand(M, N, seed=11)
+    acc = A.double() @ W.double().T + bias.double()
+    ref = O.gelu_erf(acc) if epi == 1 else (R.double() + acc if epi == 2 else acc)
+    Ad, Wd, bd, Rd = A.to(DEV), W.to(DEV), bias.to(DEV), R.to(DEV)
+    C = Rd.clone() if epi == 2 else torch.zeros(M, N, device=DEV)
+    _lib.check(_lib.lib().vitseg_op_linear_f32x3(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), C.data_ptr() if epi == 2 else None,
+                                                 C.data_ptr(), M, N, K, epi, _stream()))
+    scale = (A.abs().double() @ W.abs().double().T)
+    err = ((C.cpu().double() - ref).abs() / (scale + 1e-3)).max().item()
+    assert err < 1e-6, err
+    # against the true-fp32 kernel: they agree to fp32 accumulation noise (which grows with sqrt(K) in that kernel's
+    # sequential 32x32x2 chains; the 16-wide half MFMAs of the split path accumulate fewer, wider steps)
+    C32 = Rd.clone() if epi == 2 else torch.zeros(M, N, device=DEV)
+    _lib.check(_lib.lib().vitseg_op_linear_f32(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), C32.data_ptr() if epi == 2 else None,
+                                               C32.data_ptr(), M, N, K, epi, _stream()))
+    assert ((C - C32).abs().cpu().double() / (scale + 1e-3)).max().item() < 1e-5

@@ -102,7 +102,15 @@ __device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const ARow<T>& r, int
 // backward GEMMs meet (dgrad reads W as [n][k] with n the reduction; wgrad reads dY and X with the token
 // index as the reduction).  T-form tiles are staged as [32 k][128 rows] and read one float per lane per
 // MFMA (conflict-free: consecutive lanes = consecutive rows), so no transposed copies are ever made.
-template <typename T, typename OutT, int AMODE, int EPI, int MI, int NI, int TA = 0, int TB = 0>
+//
+// X3 (fp32 operands only): "fp32 on the fp16 matrix pipe".  Every operand value is split while it is staged,
+// a = hi + lo * 2^-11 with hi = half(a), lo = half((a - hi) * 2^11) (22 significand bits, the scaled low part stays a
+// normal half), and the product is accumulated as  acc0 += hi.hi',  acc1 += lo.hi' + hi.lo'  with
+// v_mfma_f32_32x32x16_f16 (fp32 accumulate); C = acc0 + acc1 * 2^-11.  Dropped: lo.lo' (2^-22 relative) and the
+// rounding of the low parts (2^-22): products are good to ~2^-21 instead of exact, at 3 half-precision MFMAs per
+// 16 k instead of 8 fp32 ones (16x slower each).  The hi / lo planes share the 16 KiB an fp32 operand tile uses
+// (64-byte rows, chunk index XOR-swizzled with (row >> 1) & 3), so buffering, loaders and epilogue are unchanged.
+template <typename T, typename OutT, int AMODE, int EPI, int MI, int NI, int TA = 0, int TB = 0, int X3 = 0>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM * BKF], int m0, int n0, int a_row0,
                                           int b_col0) {
     constexpr int CE = Elem<T>::CE, BKE = Elem<T>::BKE;
@@ -118,6 +126,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     static_assert(sizeof(T) == 4 || (TA == 0 && TB == 0), "T-form operands are implemented for fp32 only");
+    static_assert(!X3 || (sizeof(T) == 4 && TA == 0 && TB == 0), "X3 splits N-form fp32 operands");
+    f32x16 acc1[X3 ? MI : 1][X3 ? NI : 1];  // X3: the 2^-11-weighted cross terms
+    if constexpr (X3) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[mi][ni][r] = 0.f;
+    }
     const int li = lane & 31, lh = lane >> 5;
     const int sw = (li >> 1) & 7;
     const int a_off = TA ? a_row0 + li : (a_row0 + li) * BK, b_off = TB ? b_col0 + li : (b_col0 + li) * BK;
@@ -227,14 +245,90 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
         };
         const int wpos = lr * BK + ((lc ^ ((lr >> 1) & 7)) << 2);  // N-form; + 32*i rows -> same swizzle term
         const int tpos = tr * BM + tc * 4;                          // T-form: [k][128], + 8*i k-rows
+        // X3: row r of an operand tile = 64 B of hi halves (plane 0, first 8 KiB) and 64 B of lo halves (plane 1);
+        // this thread's 4 floats are half `lc & 1` of 16-byte chunk `lc >> 1`, stored at chunk ^ ((r >> 1) & 3)
+        const int xpos = lr * 16 + ((((lc >> 1) ^ ((lr >> 1) & 3)) << 2) | ((lc & 1) << 1));  // in 4-byte words
+        auto split = [&](const f32x4& v, uint2& hi, uint2& lo) {
+            const _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
+            hi.x = __builtin_bit_cast(unsigned, f16x2{h0, h1});
+            hi.y = __builtin_bit_cast(unsigned, f16x2{h2, h3});
+            lo.x = H16<f16_t>::pack2((v[0] - (float)h0) * 2048.f, (v[1] - (float)h1) * 2048.f);
+            lo.y = H16<f16_t>::pack2((v[2] - (float)h2) * 2048.f, (v[3] - (float)h3) * 2048.f);
+        };
         auto swrite = [&](int buf) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                *(f32x4*)&lds[buf][0][TA ? tpos + 8 * i * BM : wpos + 32 * i * BK] = oka[i] ? ra[i] : z;
-                *(f32x4*)&lds[buf][1][TB ? tpos + 8 * i * BN : wpos + 32 * i * BK] = okb[i] ? rb[i] : z;
+                if constexpr (X3) {
+                    uint2 hi, lo;
+                    split(oka[i] ? ra[i] : z, hi, lo);
+                    *(uint2*)&lds[buf][0][xpos + 32 * i * 16] = hi;
+                    *(uint2*)&lds[buf][0][2048 + xpos + 32 * i * 16] = lo;
+                    split(okb[i] ? rb[i] : z, hi, lo);
+                    *(uint2*)&lds[buf][1][xpos + 32 * i * 16] = hi;
+                    *(uint2*)&lds[buf][1][2048 + xpos + 32 * i * 16] = lo;
+                } else {
+                    *(f32x4*)&lds[buf][0][TA ? tpos + 8 * i * BM : wpos + 32 * i * BK] = oka[i] ? ra[i] : z;
+                    *(f32x4*)&lds[buf][1][TB ? tpos + 8 * i * BN : wpos + 32 * i * BK] = okb[i] ? rb[i] : z;
+                }
             }
         };
+        if constexpr (X3) {
+            // two 16-k steps per staged tile; per step and operand one hi and one lo fragment (16 B = 8 halves)
+            f32x4 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+            const int xsw = (li >> 1) & 3;
+            auto lfragx = [&](int buf, int st, int slot) {
+                const int ch = ((2 * st + lh) ^ xsw) << 2;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float* r = &lds[buf][0][(a_row0 + li + mi * 32) * 16 + ch];
+                    ah[slot][mi] = *(const f32x4*)r;
+                    al[slot][mi] = *(const f32x4*)(r + 2048);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float* r = &lds[buf][1][(b_col0 + li + ni * 32) * 16 + ch];
+                    bh[slot][ni] = *(const f32x4*)r;
+                    bl[slot][ni] = *(const f32x4*)(r + 2048);
+                }
+            };
+            auto mfmax = [&](int slot) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot][mi]), xl = __builtin_bit_cast(bf16x8, al[slot][mi]);
+                        const bf16x8 yh = __builtin_bit_cast(bf16x8, bh[slot][ni]), yl = __builtin_bit_cast(bf16x8, bl[slot][ni]);
+                        acc[mi][ni] = H16<f16_t>::mfma(xh, yh, acc[mi][ni]);
+                        acc1[mi][ni] = H16<f16_t>::mfma(xl, yh, acc1[mi][ni]);
+                        acc1[mi][ni] = H16<f16_t>::mfma(xh, yl, acc1[mi][ni]);
+                    }
+            };
+            gload(0);
+            swrite(0);
+            __syncthreads();
+            lfragx(0, 0, 0);
+            for (int kt = 0; kt < KT; ++kt) {
+                const int buf = kt & 1;
+                const int kn = min(kt + 1, KT - 1);
+                gload(kn);
+                lfragx(buf, 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmax(0);
+                __builtin_amdgcn_sched_barrier(0);
+                swrite(buf ^ 1);   // split + store of the next tile (VALU) in the shadow of the MFMAs around it
+                __syncthreads();
+                lfragx(buf ^ 1, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmax(1);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaf(acc1[mi][ni][r], 1.0f / 2048.0f, acc[mi][ni][r]);
+        } else {
         gload(0);
         swrite(0);
         __syncthreads();
@@ -264,6 +358,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
             lfrag(buf ^ 1, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             mfma_group(1, 0, 4);
+        }
         }
     } else {
         // ---- bf16: global -> LDS directly (global_load_lds_dwordx4), no staging registers, no VALU ----
@@ -431,7 +526,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
     }
 }
 
-template <typename T, typename OutT, int AMODE, int EPI, int TA = 0, int TB = 0>
+template <typename T, typename OutT, int AMODE, int EPI, int TA = 0, int TB = 0, int X3 = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][BM * BKF];  // [buffer][A|W][row*32 + swizzled chunk]
 
@@ -463,11 +558,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int rows_valid = p.M - m0;
     if (rows_valid <= 32)
-        gemm_tile<T, OutT, AMODE, EPI, 1, 1, TA, TB>(p, lds, m0, n0, 0, wave * 32);
+        gemm_tile<T, OutT, AMODE, EPI, 1, 1, TA, TB, X3>(p, lds, m0, n0, 0, wave * 32);
     else if (rows_valid <= 64)
-        gemm_tile<T, OutT, AMODE, EPI, 2, 1, TA, TB>(p, lds, m0, n0, 0, wave * 32);
+        gemm_tile<T, OutT, AMODE, EPI, 2, 1, TA, TB, X3>(p, lds, m0, n0, 0, wave * 32);
     else
-        gemm_tile<T, OutT, AMODE, EPI, 2, 2, TA, TB>(p, lds, m0, n0, (wave >> 1) * 64, (wave & 1) * 64);
+        gemm_tile<T, OutT, AMODE, EPI, 2, 2, TA, TB, X3>(p, lds, m0, n0, (wave >> 1) * 64, (wave & 1) * 64);
 }
 
 inline int env_gn() {  // experiments only: VITSEG_GN=<n> forces the column-group width of the tile order
@@ -475,24 +570,42 @@ inline int env_gn() {  // experiments only: VITSEG_GN=<n> forces the column-grou
     return v;
 }
 
-template <typename T, typename OutT, int AMODE, int EPI, int TA = 0, int TB = 0>
+template <typename T, typename OutT, int AMODE, int EPI, int TA = 0, int TB = 0, int X3 = 0>
 int launch_one(GemmArgs a, hipStream_t s) {
     if (a.ldw == 0) a.ldw = TB ? a.N : a.K;
     if (!a.gn) a.gn = env_gn();
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int splits = a.splitk > 1 ? a.splitk : 1;
-    hipLaunchKernelGGL((gemm_kernel<T, OutT, AMODE, EPI, TA, TB>), dim3(tiles, splits), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel<T, OutT, AMODE, EPI, TA, TB, X3>), dim3(tiles, splits), dim3(256), 0, s, a);
     VITSEG_LAUNCH_CHECK("gemm");
     return VITSEG_OK;
 }
 
 }  // namespace
 
-int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s) {
+int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s, bool x3) {
     VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 4 == 0, VITSEG_EINVAL, "gemm_f32: bad M/N/K %d %d %d", a.M,
                      a.N, a.K);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm: N=%d and ldc=%d must be multiples of 4", a.N,
                      a.ldc);
+    if (x3) {  // fp32 operands split into half pairs on the fly, 3 fp16 MFMAs per product (see gemm_tile, X3)
+        if (amode == A_PLAIN) {
+            VITSEG_CHECK_ARG(a.lda % 4 == 0, VITSEG_EINVAL, "gemm_f32: lda %% 4");
+            switch (epi) {
+                case EPI_BIAS: return launch_one<float, float, A_PLAIN, EPI_BIAS, 0, 0, 1>(a, s);
+                case EPI_GELU: return launch_one<float, float, A_PLAIN, EPI_GELU, 0, 0, 1>(a, s);
+                case EPI_RESADD: return launch_one<float, float, A_PLAIN, EPI_RESADD, 0, 0, 1>(a, s);
+            }
+        } else if (amode == A_PATCH && epi == EPI_POS) {
+            VITSEG_CHECK_ARG(a.P % 4 == 0, VITSEG_ESHAPE, "patch size must be a multiple of 4");
+            return launch_one<float, float, A_PATCH, EPI_POS, 0, 0, 1>(a, s);
+        } else if (amode == A_CONV3 && epi == EPI_RELU) {
+            VITSEG_CHECK_ARG(a.D % 4 == 0, VITSEG_ESHAPE, "hidden size must be a multiple of 4");
+            return launch_one<float, float, A_CONV3, EPI_RELU, 0, 0, 1>(a, s);
+        }
+        set_error("gemm_f32 (x3): unsupported amode/epilogue %d/%d", amode, epi);
+        return VITSEG_EINVAL;
+    }
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 4 == 0, VITSEG_EINVAL, "gemm_f32: lda %% 4");
         switch (epi) {

@@ -40,7 +40,8 @@ struct GemmArgs {
     DropArgs drop;        // EPI_RESADD: C = R + dropout(acc + bias)   (hidden dropout, modeling_vit.py:276,283)
 };
 
-int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s);
+// x3: fp32 operands split into half pairs while staged, 3 fp16 MFMAs per product (fp32-grade results, gemm.hip X3)
+int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s, bool x3 = false);
 int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, hipStream_t s);
 size_t wgrad_scratch_floats(int M, int N, int K);
 int launch_wgrad_f32(GemmArgs a, float* scratch, hipStream_t s);

@@ -39,7 +39,7 @@ Plan make_plan(const Shape& s, int B, int precision) {
     Plan p{};
     p.Mp = (size_t)B * s.Np;
     p.Mt = p.Mp + B;
-    const size_t act = precision == VITSEG_F32 ? 4 : 2;
+    const size_t act = (precision == VITSEG_F32 || precision == VITSEG_F32X3) ? 4 : 2;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t o = off;
@@ -149,7 +149,7 @@ int vitseg_query_workspace(const vitseg_config* cfg, int batch, int precision, s
     Shape s;
     if (int rc = check_config(cfg, &s)) return rc;
     VITSEG_CHECK_ARG(batch >= 1 && bytes, VITSEG_EINVAL, "batch %d / null out pointer", batch);
-    VITSEG_CHECK_ARG(precision >= VITSEG_F32 && precision <= VITSEG_F16, VITSEG_EINVAL, "precision %d", precision);
+    VITSEG_CHECK_ARG(precision >= VITSEG_F32 && precision <= VITSEG_F32X3, VITSEG_EINVAL, "precision %d", precision);
     *bytes = make_plan(s, batch, precision).total;
     return VITSEG_OK;
 }
@@ -178,11 +178,13 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     if (int rc = check_config(cfg, &s)) return rc;
     VITSEG_CHECK_ARG(params && x && workspace && batch >= 1, VITSEG_EINVAL, "null pointer or batch < 1");
     VITSEG_CHECK_ARG(logits || mask, VITSEG_EINVAL, "both outputs are null");
-    VITSEG_CHECK_ARG(precision >= VITSEG_F32 && precision <= VITSEG_F16, VITSEG_EINVAL, "precision %d", precision);
-    VITSEG_CHECK_ARG(precision == VITSEG_F32 || params_bf16, VITSEG_EINVAL, "16-bit forward needs the 16-bit arena");
+    VITSEG_CHECK_ARG(precision >= VITSEG_F32 && precision <= VITSEG_F32X3, VITSEG_EINVAL, "precision %d", precision);
+    VITSEG_CHECK_ARG(precision == VITSEG_F32 || precision == VITSEG_F32X3 || params_bf16, VITSEG_EINVAL,
+                     "16-bit forward needs the 16-bit arena");
     VITSEG_CHECK_ARG(((uintptr_t)params | (uintptr_t)x | (uintptr_t)workspace | (uintptr_t)logits) % 16 == 0,
                      VITSEG_EINVAL, "pointers must be 16-byte aligned");
-    const bool lp = precision != VITSEG_F32, f16 = precision == VITSEG_F16;
+    const bool x3 = precision == VITSEG_F32X3;  // fp32 storage, GEMMs on the fp16 pipe with split operands
+    const bool lp = precision == VITSEG_BF16 || precision == VITSEG_F16, f16 = precision == VITSEG_F16;
     const Plan p = make_plan(s, batch, precision);
     VITSEG_CHECK_ARG(workspace_bytes >= p.total, VITSEG_EWORKSPACE, "workspace %zu < required %zu", workspace_bytes,
                      p.total);
@@ -212,7 +214,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
         {
             ProfScope ps(VITSEG_K_GEMM_PATCH, 2.0 * g.M * g.N * g.K, st);
-            if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st))) return rc;
+            if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st, x3))) return rc;
         }
         if ((rc = launch_cls_rows(W(VITSEG_T_CLS), W(VITSEG_T_POS), X, batch, s.Np, D, st))) return rc;
     }
@@ -220,7 +222,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     const double ln_bytes = 2.0 * Mt * D * 4;
     auto gemm = [&](const GemmArgs& g, int epi, int kind) {
         ProfScope ps(kind, 2.0 * g.M * g.N * g.K, st);
-        return lp ? launch_gemm_bf16(g, A_PLAIN, epi, st, f16) : launch_gemm_f32(g, A_PLAIN, epi, st);
+        return lp ? launch_gemm_bf16(g, A_PLAIN, epi, st, f16) : launch_gemm_f32(g, A_PLAIN, epi, st, x3);
     };
     auto lnorm = [&](const float* w, const float* b, int rows) {
         ProfScope ps(VITSEG_K_LAYERNORM, (double)rows * D * (lp ? 6 : 8), st);
@@ -268,7 +270,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         }
         {
             ProfScope ps(VITSEG_K_GEMM_CONV3, 2.0 * g.M * g.N * g.K, st);
-            rc = lp ? launch_gemm_bf16(g, A_CONV3, EPI_RELU, st, f16) : launch_gemm_f32(g, A_CONV3, EPI_RELU, st);
+            rc = lp ? launch_gemm_bf16(g, A_CONV3, EPI_RELU, st, f16) : launch_gemm_f32(g, A_CONV3, EPI_RELU, st, x3);
             if (rc) return rc;
         }
         ProfScope ps(VITSEG_K_HEAD1X1, (double)Mp * MID * 4 + (double)batch * s.C * s.Np * 4, st);
@@ -343,6 +345,17 @@ int vitseg_op_linear_bf16(const void* A, const void* Wt, const float* bias, cons
     g.A = A; g.W = Wt; g.bias = bias; g.R = R; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
     return launch_gemm_bf16(g, A_PLAIN, epilogue, (hipStream_t)stream);
+}
+
+int vitseg_op_linear_f32x3(const float* A, const float* Wt, const float* bias, const float* R, float* C, int M, int N,
+                           int K, int epilogue, void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "linear: null pointer");
+    VITSEG_CHECK_ARG(epilogue >= 0 && epilogue <= 2, VITSEG_EINVAL, "linear_f32x3: epilogue %d", epilogue);
+    VITSEG_CHECK_ARG(epilogue != EPI_RESADD || R, VITSEG_EINVAL, "linear: residual epilogue needs R");
+    GemmArgs g{};
+    g.A = A; g.W = Wt; g.bias = bias; g.R = R; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
+    return launch_gemm_f32(g, A_PLAIN, epilogue, (hipStream_t)stream, true);
 }
 
 int vitseg_op_linear_f16(const void* A, const void* Wt, const float* bias, const float* R, void* C, int M, int N, int K,

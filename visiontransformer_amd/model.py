@@ -19,7 +19,8 @@ from . import _lib, params as _params
 from .config import ViTSegConfig
 
 _PRECISION = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.BF16, "bfloat16": _lib.BF16,
-              "fp16": _lib.F16, "f16": _lib.F16, "float16": _lib.F16, "half": _lib.F16}
+              "fp16": _lib.F16, "f16": _lib.F16, "float16": _lib.F16, "half": _lib.F16,
+              "fp32x3": _lib.F32X3, "f32x3": _lib.F32X3}
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -179,7 +180,7 @@ class ViTSegmentationModel(nn.Module):
     def _bf16_arena(self):
         """16-bit shadow of the arena in the format of `self.precision` (bf16 or IEEE half), refreshed when the
         fp32 master changes."""
-        if self.precision == _lib.F32:
+        if self.precision in (_lib.F32, _lib.F32X3):
             return None
         ver = (self.arena._version, self.arena.data_ptr())
         if self._arena_bf16 is None or self._bf16_version != ver:
