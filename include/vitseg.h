@@ -143,6 +143,7 @@ int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patc
 /* fp32 in / fp32 out through the split-operand fp16 MFMA path of VITSEG_F32X3 (same arguments as linear_f32) */
 int vitseg_op_linear_f32x3(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
                            int K, int epilogue, void* stream);
+int vitseg_op_attention_f32x3(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream);
 /* IEEE-half variants of the two above (operands as raw fp16 bits) */
 int vitseg_op_linear_f16(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K,
                          int epilogue, void* stream);

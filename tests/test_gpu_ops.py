@@ -208,3 +208,29 @@ def test_linear_f32x3_is_fp32_grade(M, N, K, epi):
     _lib.check(_lib.lib().vitseg_op_linear_f32(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), C32.data_ptr() if epi == 2 else None,
                                                C32.data_ptr(), M, N, K, epi, _stream()))
     assert ((C - C32).abs().cpu().double() / (scale + 1e-3)).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,Np,A", [(2, 196, 3), (1, 1024, 2), (3, 784, 1), (1, 64, 1), (2, 128, 12), (1, 200, 2)])
+def test_attention_f32x3_is_fp32_grade(B, Np, A):
+    """Split-operand attention (attention_x3.hip): fp32 in / fp32 out, QK^T and PV as 3 half MFMAs per product.
+    Same inputs and same tolerance as the exact-fp32 kernel's test."""
+    D = 64 * A
+    Mt = B * Np + B
+    qkv = _rand(Mt, 3 * D, seed=Np + A, scale=1.5)
+    qkv[Np // 2, :64] *= 6.0                       # a peaked softmax row
+    qkv[(Np * 3) // 4, D:D + 64] = qkv[Np // 2, :64]
+    ref = torch.empty(Mt, D, dtype=torch.float64)
+    x64 = qkv.double()
+    for b in range(B):
+        r = torch.cat([torch.tensor([B * Np + b]), torch.arange(b * Np, (b + 1) * Np)])
+        q, k, v = [x64[r][:, i * D:(i + 1) * D].reshape(Np + 1, A, 64).transpose(0, 1) for i in range(3)]
+        s = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+        ref[r] = (s @ v).transpose(0, 1).reshape(Np + 1, D)
+    qd = qkv.to(DEV)
+    ctx = torch.full((Mt, D), float("nan"), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_attention_f32x3(qd.data_ptr(), ctx.data_ptr(), B, Np, A, _stream()))
+    err = (ctx.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5, err
+    ctx32 = torch.empty_like(ctx)
+    _lib.check(_lib.lib().vitseg_op_attention_f32(qd.data_ptr(), ctx32.data_ptr(), B, Np, A, _stream()))
+    print(f"attention x3 max err {err:.2e}, exact-fp32 kernel {(ctx32.cpu().double() - ref).abs().max().item():.2e}")

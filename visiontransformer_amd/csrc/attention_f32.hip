@@ -317,13 +317,18 @@ __global__ __launch_bounds__(1024) void attn_cls_f32_kernel(const float* __restr
 
 }  // namespace
 
-int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s) {
+int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s,
+                         bool x3) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_f32: bad arguments");
     const dim3 grid((unsigned)((Np + QB - 1) / QB) * A * B);  // 1-D: attn_tile() places the tiles
-    if (Np % QB == 0)
+    if (x3) {  // VITSEG_F32X3 (inference): patch queries on the fp16 pipe with split operands, attention_x3.hip
+        VITSEG_CHECK_ARG(!lse && !dr.thresh, VITSEG_EINVAL, "attention (x3) is an inference path: no lse / dropout");
+        if (int rc = launch_attention_x3_main(qkv, ctx, B, Np, A, s)) return rc;
+    } else if (Np % QB == 0) {
         hipLaunchKernelGGL(attn_f32_kernel<false>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr);
-    else
+    } else {
         hipLaunchKernelGGL(attn_f32_kernel<true>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr);
+    }
     VITSEG_LAUNCH_CHECK("attn_f32");
     const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 64 * 64) * sizeof(float);
     VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_f32: sequence too long for the CLS kernel");

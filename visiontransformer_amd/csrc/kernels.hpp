@@ -57,7 +57,9 @@ int launch_layernorm(const float* x, const float* w, const float* b, void* y, in
 
 // Multi-head self-attention core (a6) on the patches-first row layout.
 // lse (optional): fp32 [B, A, Np+1] log2-domain log-sum-exp per query (CLS last), saved for the backward
-int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s);
+int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s,
+                         bool x3 = false);
+int launch_attention_x3_main(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s);
 // dqkv[Mt,3D] from dctx[Mt,D]; dvec: scratch fp32 [B, A, Np+1]
 int launch_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dvec,
                              float* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s);

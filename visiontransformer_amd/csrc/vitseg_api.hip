@@ -238,7 +238,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         {
             ProfScope ps(VITSEG_K_ATTENTION, 4.0 * batch * s.A * (double)s.N * s.N * 64, st);
             rc = lp ? launch_attention_bf16(QKV, H, nullptr, batch, s.Np, s.A, DropArgs{}, st, f16)
-                    : launch_attention_f32((const float*)QKV, (float*)H, nullptr, batch, s.Np, s.A, DropArgs{}, st);
+                    : launch_attention_f32((const float*)QKV, (float*)H, nullptr, batch, s.Np, s.A, DropArgs{}, st, x3);
             if (rc) return rc;
         }
         g = GemmArgs{};
@@ -400,6 +400,10 @@ int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patc
 int vitseg_op_attention_f16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream) {
     return launch_attention_bf16(qkv, ctx, nullptr, batch, num_patches, num_heads, DropArgs{}, (hipStream_t)stream,
                                  true);
+}
+
+int vitseg_op_attention_f32x3(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
+    return launch_attention_f32(qkv, ctx, nullptr, batch, num_patches, num_heads, DropArgs{}, (hipStream_t)stream, true);
 }
 
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
