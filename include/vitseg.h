@@ -111,6 +111,10 @@ int vitseg_param_offset(const vitseg_config* cfg, int tensor, int layer, size_t*
 
 /* fp32 arena -> bf16 shadow arena (same offsets, 2 bytes/elt); needed before a VITSEG_BF16 forward. */
 int vitseg_cast_params_bf16(const float* params, void* params_bf16, size_t n_floats, void* stream);
+/* fp32 arena -> split arena for VITSEG_F32X3 (optional; same size and offsets as the fp32 arena: every 4 values become
+ * 4 hi halves | 4 scaled lo halves).  Passed in the params_bf16 slot it spares the GEMMs the weight half of the
+ * operand splitting; with NULL there they split the fp32 weights themselves. */
+int vitseg_cast_params_split(const float* params, void* params_split, size_t n_floats, void* stream);
 /* same for IEEE half (VITSEG_F16); the shadow arena is passed in the params_bf16 slot of vitseg_forward */
 int vitseg_cast_params_f16(const float* params, void* params_f16, size_t n_floats, void* stream);
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "vitseg_ce_scratch_bytes", "vitseg_ce_loss",
     "vitseg_train_workspace", "vitseg_forward_train", "vitseg_backward", "vitseg_adam_step",
     "vitseg_grad_bucket_count", "vitseg_grad_bucket_range",
-    "vitseg_cast_params_f16", "vitseg_op_linear_f16", "vitseg_op_attention_f16", "vitseg_op_linear_f32x3", "vitseg_op_attention_f32x3",
+    "vitseg_cast_params_f16", "vitseg_op_linear_f16", "vitseg_op_attention_f16", "vitseg_op_linear_f32x3", "vitseg_op_attention_f32x3", "vitseg_cast_params_split",
     "vitseg_resize_taps", "vitseg_resize_coeffs", "vitseg_nearest_index", "vitseg_preprocess_u8",
     "vitseg_resize_nearest_u8", "vitseg_eval_counts", "vitseg_paed_scratch_bytes", "vitseg_paed_multiclass_loss",
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32",
@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
         l.vitseg_param_offset.argtypes = [pcfg, i32, i32, psz, psz]
         l.vitseg_cast_params_bf16.argtypes = [vp, vp, sz, vp]
         l.vitseg_cast_params_f16.argtypes = [vp, vp, sz, vp]
+        l.vitseg_cast_params_split.argtypes = [vp, vp, sz, vp]
         l.vitseg_query_workspace.argtypes = [pcfg, i32, i32, psz]
         l.vitseg_workspace_offset.argtypes = [pcfg, i32, i32, i32, psz, psz]
         l.vitseg_forward.argtypes = [pcfg, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]

@@ -264,7 +264,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                     split(oka[i] ? ra[i] : z, hi, lo);
                     *(uint2*)&lds[buf][0][xpos + 32 * i * 16] = hi;
                     *(uint2*)&lds[buf][0][2048 + xpos + 32 * i * 16] = lo;
-                    split(okb[i] ? rb[i] : z, hi, lo);
+                    if constexpr (X3 == 2) {  // weights pre-split (vitseg_cast_params_split): 16 B = 4 hi halves | 4 lo halves
+                        const f32x4 w = okb[i] ? rb[i] : z;
+                        hi = uint2{__float_as_uint(w[0]), __float_as_uint(w[1])};
+                        lo = uint2{__float_as_uint(w[2]), __float_as_uint(w[3])};
+                    } else {
+                        split(okb[i] ? rb[i] : z, hi, lo);
+                    }
                     *(uint2*)&lds[buf][1][xpos + 32 * i * 16] = hi;
                     *(uint2*)&lds[buf][1][2048 + xpos + 32 * i * 16] = lo;
                 } else {
@@ -583,12 +589,32 @@ int launch_one(GemmArgs a, hipStream_t s) {
 
 }  // namespace
 
-int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s, bool x3) {
+int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s, int x3) {
     VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 4 == 0, VITSEG_EINVAL, "gemm_f32: bad M/N/K %d %d %d", a.M,
                      a.N, a.K);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm: N=%d and ldc=%d must be multiples of 4", a.N,
                      a.ldc);
-    if (x3) {  // fp32 operands split into half pairs on the fly, 3 fp16 MFMAs per product (see gemm_tile, X3)
+    // x3 = 1: both fp32 operands are split into half pairs on the fly; 2: W is the pre-split shadow arena
+    // (vitseg_cast_params_split), only A is split in the kernel.  3 fp16 MFMAs per product (see gemm_tile, X3)
+    if (x3 == 2) {
+        if (amode == A_PLAIN) {
+            VITSEG_CHECK_ARG(a.lda % 4 == 0, VITSEG_EINVAL, "gemm_f32: lda %% 4");
+            switch (epi) {
+                case EPI_BIAS: return launch_one<float, float, A_PLAIN, EPI_BIAS, 0, 0, 2>(a, s);
+                case EPI_GELU: return launch_one<float, float, A_PLAIN, EPI_GELU, 0, 0, 2>(a, s);
+                case EPI_RESADD: return launch_one<float, float, A_PLAIN, EPI_RESADD, 0, 0, 2>(a, s);
+            }
+        } else if (amode == A_PATCH && epi == EPI_POS) {
+            VITSEG_CHECK_ARG(a.P % 4 == 0, VITSEG_ESHAPE, "patch size must be a multiple of 4");
+            return launch_one<float, float, A_PATCH, EPI_POS, 0, 0, 2>(a, s);
+        } else if (amode == A_CONV3 && epi == EPI_RELU) {
+            VITSEG_CHECK_ARG(a.D % 4 == 0, VITSEG_ESHAPE, "hidden size must be a multiple of 4");
+            return launch_one<float, float, A_CONV3, EPI_RELU, 0, 0, 2>(a, s);
+        }
+        set_error("gemm_f32 (x3, split W): unsupported amode/epilogue %d/%d", amode, epi);
+        return VITSEG_EINVAL;
+    }
+    if (x3 == 1) {  // fp32 operands split into half pairs on the fly, 3 fp16 MFMAs per product (see gemm_tile, X3)
         if (amode == A_PLAIN) {
             VITSEG_CHECK_ARG(a.lda % 4 == 0, VITSEG_EINVAL, "gemm_f32: lda %% 4");
             switch (epi) {
@@ -646,20 +672,31 @@ constexpr int LBM = 256;
 // LBN = 128: waves 4(M) x 2(N), 64x64 per wave, 3-stage ring (3 x 48 KiB), 85 FLOP per staged byte.
 // LBN = 256: waves 2(M) x 4(N), 128x64 per wave (128 accumulator registers), 2-stage ring (2 x 64 KiB),
 //            128 FLOP per staged byte -- half the L2->LDS traffic of the 128x128 kernel, which is what bounds it.
-template <typename T, typename OutT, int AMODE, int EPI, int LBN>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs p) {
+// LBN = 256, WAVES = 4: waves 2(M) x 2(N), 128x128 per wave (256 accumulator registers, ONE wave per SIMD with the
+//            whole 512-register file).  At 32 clk per 32x32x16 MFMA a wave tile of MI x NI blocks reads
+//            (MI + NI) KiB of fragments per MI * NI MFMAs; with the four matrix pipes of a CU busy that is
+//            128 * (MI + NI) / (MI * NI) bytes/clk of LDS reads against a 128 B/clk LDS: 2x2 tiles need all of it
+//            (the 128x128 kernel's ~50 % ceiling), 4x2 needs 96, 4x4 needs 64.  Measured (tools/tile_sweep.sh): correct, but
+//            7-11 % SLOWER than the 8-wave 256x256 tile on every model shape -- with a single wave per SIMD nothing
+//            covers its barrier and LDS-latency stalls.  Kept selectable (VITSEG_BF16_TILES=4w) as the starting point
+//            of a finer-phased pipeline; never picked by default.
+template <typename T, typename OutT, int AMODE, int EPI, int LBN, int WAVES = 8>
+__global__ __launch_bounds__(WAVES * 64) void gemm_bf16_large_kernel(const GemmArgs p) {
     constexpr int CE = 8, BKE = 64, BK = BKF;
     constexpr int STAGES = LBN == 128 ? 3 : 2;
-    constexpr int MI = LBN == 128 ? 2 : 4, NI = 2;      // 32x32 MFMA tiles per wave
+    constexpr int MI = LBN == 128 ? 2 : 4, NI = WAVES == 4 ? 4 : 2;      // 32x32 MFMA tiles per wave
     constexpr int WROWS = MI * 32;                       // rows per wave
-    constexpr int WPW = LBN / 64;                        // W DMA pieces per wave (8 rows each)
+    constexpr int APW = LBM / 8 / WAVES;                 // A DMA pieces per wave (8 rows each)
+    constexpr int WPW = LBN / 8 / WAVES;                 // W DMA pieces per wave
+    static_assert(WAVES == 8 || (WAVES == 4 && LBN == 256), "4 waves: the 256x256 tile only");
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [stage][A 256 rows | W LBN rows][32 words]
     auto stageA = [&](int st) { return lds_raw + st * (LBM + LBN) * BK; };
     auto stageW = [&](int st) { return lds_raw + st * (LBM + LBN) * BK + LBM * BK; };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches below
-    const int wm = LBN == 128 ? wave >> 1 : wave >> 2, wn = LBN == 128 ? wave & 1 : wave & 3;
+    const int wm = WAVES == 4 ? wave >> 1 : (LBN == 128 ? wave >> 1 : wave >> 2);
+    const int wn = WAVES == 4 ? wave & 1 : (LBN == 128 ? wave & 1 : wave & 3);
     const int tiles_n = (p.N + LBN - 1) / LBN, tiles_m = (p.M + LBM - 1) / LBM;
     int t = xcd_remap(blockIdx.x, gridDim.x);
     const int GN = p.gn ? p.gn : (LBN == 128 ? ((size_t)p.K * sizeof(T) <= 2048 ? 8 : 4) : 4);
@@ -682,12 +719,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
     const bool computes = (p.M - m0 > 64) || wm == 0;  // thin tile: only the first 64 rows exist
 
     // ---- DMA assignment: per K step 32 A pieces + LBN/8 W pieces of 1 KiB (8 rows each) ----
-    const T* asrc[4];
+    const T* asrc[APW];
     const T* wsrc[WPW];
-    int ay[4], ax[4];
+    int ay[APW], ax[APW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < APW; ++i) {
+        const int row = (wave * APW + i) * 8 + (lane >> 3);
         const int cpos = (lane & 7) ^ ((row >> 1) & 7);
         const int m = min(m0 + row, p.M - 1);
         if (AMODE == A_PLAIN) {
@@ -716,7 +753,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
             kx = tap - ky * 3;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < APW; ++i) {
             const T* ga;
             if (AMODE == A_PLAIN) {
                 ga = asrc[i] + k0;
@@ -726,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
                 ga = in ? asrc[i] + ((ptrdiff_t)(ky - 1) * p.g + (kx - 1)) * p.D + d0 : (const T*)p.zeros + (lane & 7) * CE;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
-                                             (__attribute__((address_space(3))) void*)(stageA(st) + (wave * 4 + i) * 8 * BK),
+                                             (__attribute__((address_space(3))) void*)(stageA(st) + (wave * APW + i) * 8 * BK),
                                              16, 0, 0);
         }
 #pragma unroll
@@ -745,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     const int li = lane & 31, lh = lane >> 5;
     const int sw = (li >> 1) & 7;
-    const int a_off = (wm * WROWS + li) * BK, b_off = (wn * 64 + li) * BK;
+    const int a_off = (wm * WROWS + li) * BK, b_off = (wn * NI * 32 + li) * BK;
     f32x4 a[2][MI], b[2][NI];
     auto lfrag = [&](int st, int j, int slot) {
         const int ch = (((2 * j + lh) ^ sw) << 2);
@@ -818,19 +855,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
     if (!computes) return;
     float* wl = lds_raw + wave * 4096;
     const int rr = lane >> 4, c4 = (lane & 15) * 4;
-    const int gcol = n0 + wn * 64 + c4;
+    OutT* C = (OutT*)p.C;
+#pragma unroll
+    for (int nh = 0; nh < NI / 2; ++nh) {   // 64-column halves of the wave tile
+    const int gcol = n0 + wn * NI * 32 + nh * 64 + c4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && gcol < p.N) bias4 = *(const f32x4*)(p.bias + gcol);
-    OutT* C = (OutT*)p.C;
 #pragma unroll
     for (int half = 0; half < MI / 2; ++half) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    wl[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + ni * 32 + li] = acc[half * 2 + mi][ni][r];
+                    wl[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + ni * 32 + li] = acc[half * 2 + mi][nh * 2 + ni][r];
         // all LDS reads (and residual loads) first, stores last: in a kernel that contains LDS-DMA hipcc waits
         // vmcnt(0) before every use of a ds_read result, which would serialise the stores one by one
         f32x4 v[16], extra[16];
@@ -873,9 +912,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmArgs 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private buffer is reused by the next half
     }
+    }
 }
 
-template <typename T, typename OutT, int AMODE, int EPI, int LBN = 128>
+template <typename T, typename OutT, int AMODE, int EPI, int LBN = 128, int WAVES = 8>
 int launch_large(GemmArgs a, hipStream_t s) {
     if (a.ldw == 0) a.ldw = a.K;
     if (!a.gn) a.gn = env_gn();
@@ -883,12 +923,12 @@ int launch_large(GemmArgs a, hipStream_t s) {
     const size_t smem = (size_t)(LBN == 128 ? 3 : 2) * (LBM + LBN) * BKF * sizeof(float);  // 144 / 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN, WAVES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_large)");
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN>), dim3(tiles), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN, WAVES>), dim3(tiles), dim3(WAVES * 64), smem, s, a);
     VITSEG_LAUNCH_CHECK("gemm_bf16_large");
     return VITSEG_OK;
 }
@@ -959,19 +999,23 @@ int launch_gemm_h16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
                      a.ldc);
     // the 256x128 / 3-stage kernel and the 128x128 / 2-stage kernel measure within a few % of each other on the
     // model's shapes (both ~790 TF/s asymptote); the large one is used where its deeper prefetch helps: long K
-    const char* force = getenv("VITSEG_BF16_TILES");  // "large" / "xl" / "small" for experiments
+    const char* force = getenv("VITSEG_BF16_TILES");  // "large" / "xl" / "4w" (256x256, 4 waves) / "small" for experiments
+    const bool w4 = force && force[0] == '4';
     const bool xl = force ? force[0] == 'x' : (a.M >= 8192 && a.N >= 2048);
     const bool large = force ? force[0] == 'l' : (!xl && a.M >= 4096 && a.K >= 2048);
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 8 == 0, VITSEG_EINVAL, "gemm_bf16: lda %% 8");
         switch (epi) {
-            case EPI_BIAS: return xl ? launch_large<T, T, A_PLAIN, EPI_BIAS, 256>(a, s)
+            case EPI_BIAS: return w4 ? launch_large<T, T, A_PLAIN, EPI_BIAS, 256, 4>(a, s)
+                                  : xl ? launch_large<T, T, A_PLAIN, EPI_BIAS, 256>(a, s)
                                   : large ? launch_large<T, T, A_PLAIN, EPI_BIAS>(a, s)
                                           : launch_one<T, T, A_PLAIN, EPI_BIAS>(a, s);
-            case EPI_GELU: return xl ? launch_large<T, T, A_PLAIN, EPI_GELU, 256>(a, s)
+            case EPI_GELU: return w4 ? launch_large<T, T, A_PLAIN, EPI_GELU, 256, 4>(a, s)
+                                  : xl ? launch_large<T, T, A_PLAIN, EPI_GELU, 256>(a, s)
                                   : large ? launch_large<T, T, A_PLAIN, EPI_GELU>(a, s)
                                           : launch_one<T, T, A_PLAIN, EPI_GELU>(a, s);
-            case EPI_RESADD: return xl ? launch_large<T, float, A_PLAIN, EPI_RESADD, 256>(a, s)
+            case EPI_RESADD: return w4 ? launch_large<T, float, A_PLAIN, EPI_RESADD, 256, 4>(a, s)
+                                    : xl ? launch_large<T, float, A_PLAIN, EPI_RESADD, 256>(a, s)
                                     : large ? launch_large<T, float, A_PLAIN, EPI_RESADD>(a, s)
                                             : launch_one<T, float, A_PLAIN, EPI_RESADD>(a, s);
         }

@@ -41,7 +41,7 @@ struct GemmArgs {
 };
 
 // x3: fp32 operands split into half pairs while staged, 3 fp16 MFMAs per product (fp32-grade results, gemm.hip X3)
-int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s, bool x3 = false);
+int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s, int x3 = 0);  // 1: split A and W, 2: W pre-split
 int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, hipStream_t s);
 size_t wgrad_scratch_floats(int M, int N, int K);
 int launch_wgrad_f32(GemmArgs a, float* scratch, hipStream_t s);
@@ -82,6 +82,8 @@ int launch_ce_loss(const float* Z, const void* target, int target_is_u8, float* 
 int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int Np, int D, hipStream_t s);
 
 int launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s, bool f16 = false);
+// fp32 -> per 4 values: 4 hi halves | 4 scaled lo halves (same 16 bytes, same offsets): the W operand of VITSEG_F32X3
+int launch_cast_split(const float* src, void* dst, size_t n, hipStream_t s);
 // dropout on a row-major [rows][cols] fp32 tensor: dst = keep ? src * scale : 0 (dst may alias src; dst_bf16 selects
 // a bf16 destination).  Used for the embedding dropout and for masking branch gradients in the backward.
 int launch_dropout_rows(const float* src, void* dst, int dst_bf16, int rows, int cols, DropArgs d, hipStream_t s);

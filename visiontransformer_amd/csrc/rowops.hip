@@ -89,6 +89,21 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, H* __restrict__ 
     }
 }
 
+__global__ void cast_split_kernel(const float* __restrict__ src, uint4* __restrict__ dst, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        const f32x4 v = ((const f32x4*)src)[i];
+        const _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
+        uint4 o;
+        o.x = __builtin_bit_cast(unsigned, f16x2{h0, h1});
+        o.y = __builtin_bit_cast(unsigned, f16x2{h2, h3});
+        o.z = H16<f16_t>::pack2((v[0] - (float)h0) * 2048.f, (v[1] - (float)h1) * 2048.f);
+        o.w = H16<f16_t>::pack2((v[2] - (float)h2) * 2048.f, (v[3] - (float)h3) * 2048.f);
+        dst[i] = o;
+    }
+}
+
 template <typename OutT>
 __global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restrict__ src, OutT* __restrict__ dst,
                                                            int rows, int cols4, DropArgs d) {
@@ -156,6 +171,15 @@ int launch_layernorm(const float* x, const float* w, const float* b, void* y, in
 int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int Np, int D, hipStream_t s) {
     hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, cls, pos, X, B, Np, D);
     VITSEG_LAUNCH_CHECK("cls_rows");
+    return VITSEG_OK;
+}
+
+int launch_cast_split(const float* src, void* dst, size_t n, hipStream_t s) {
+    VITSEG_CHECK_ARG(n % 4 == 0, VITSEG_EINVAL, "cast_split: n %% 4");
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cast_split_kernel, dim3(blocks), dim3(256), 0, s, src, (uint4*)dst, n4);
+    VITSEG_LAUNCH_CHECK("cast_split");
     return VITSEG_OK;
 }
 

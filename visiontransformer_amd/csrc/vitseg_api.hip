@@ -140,6 +140,11 @@ int vitseg_cast_params_bf16(const float* params, void* params_bf16, size_t n_flo
     return launch_cast_bf16(params, params_bf16, n_floats, (hipStream_t)stream);
 }
 
+int vitseg_cast_params_split(const float* params, void* params_split, size_t n_floats, void* stream) {
+    VITSEG_CHECK_ARG(params && params_split, VITSEG_EINVAL, "null arena");
+    return launch_cast_split(params, params_split, n_floats, (hipStream_t)stream);
+}
+
 int vitseg_cast_params_f16(const float* params, void* params_f16, size_t n_floats, void* stream) {
     VITSEG_CHECK_ARG(params && params_f16, VITSEG_EINVAL, "null arena");
     return launch_cast_bf16(params, params_f16, n_floats, (hipStream_t)stream, true);
@@ -183,7 +188,8 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
                      "16-bit forward needs the 16-bit arena");
     VITSEG_CHECK_ARG(((uintptr_t)params | (uintptr_t)x | (uintptr_t)workspace | (uintptr_t)logits) % 16 == 0,
                      VITSEG_EINVAL, "pointers must be 16-byte aligned");
-    const bool x3 = precision == VITSEG_F32X3;  // fp32 storage, GEMMs on the fp16 pipe with split operands
+    // fp32 storage, GEMMs on the fp16 pipe with split operands; 2 = the weights come pre-split (params_bf16 slot)
+    const int x3 = precision == VITSEG_F32X3 ? (params_bf16 ? 2 : 1) : 0;
     const bool lp = precision == VITSEG_BF16 || precision == VITSEG_F16, f16 = precision == VITSEG_F16;
     const Plan p = make_plan(s, batch, precision);
     VITSEG_CHECK_ARG(workspace_bytes >= p.total, VITSEG_EWORKSPACE, "workspace %zu < required %zu", workspace_bytes,
@@ -194,6 +200,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     // weight operand of a GEMM: fp32 arena or its bf16 shadow (same element offsets)
     auto WG = [&](int t, int layer = 0) -> const void* {
         const size_t off = tensor_offset(lay, t, layer);
+        if (x3 == 2) return (const void*)((const float*)params_bf16 + off);  // split arena: same float offsets
         return lp ? (const void*)((const unsigned short*)params_bf16 + off) : (const void*)(params + off);
     };
     char* ws = (char*)workspace;
@@ -209,7 +216,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     // ---- embeddings (a2 + a3): patch GEMM gathers straight from the NCHW image ----
     {
         GemmArgs g{};
-        g.A = x; g.W = W(VITSEG_T_PATCH_W); g.bias = W(VITSEG_T_PATCH_B); g.R = W(VITSEG_T_POS); g.C = X;
+        g.A = x; g.W = x3 == 2 ? WG(VITSEG_T_PATCH_W) : (const void*)W(VITSEG_T_PATCH_W); g.bias = W(VITSEG_T_PATCH_B); g.R = W(VITSEG_T_POS); g.C = X;
         g.M = Mp; g.N = D; g.K = s.Kp; g.lda = 0; g.ldc = D;
         g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
         {
@@ -238,7 +245,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         {
             ProfScope ps(VITSEG_K_ATTENTION, 4.0 * batch * s.A * (double)s.N * s.N * 64, st);
             rc = lp ? launch_attention_bf16(QKV, H, nullptr, batch, s.Np, s.A, DropArgs{}, st, f16)
-                    : launch_attention_f32((const float*)QKV, (float*)H, nullptr, batch, s.Np, s.A, DropArgs{}, st, x3);
+                    : launch_attention_f32((const float*)QKV, (float*)H, nullptr, batch, s.Np, s.A, DropArgs{}, st, x3 != 0);
             if (rc) return rc;
         }
         g = GemmArgs{};

@@ -178,17 +178,18 @@ class ViTSegmentationModel(nn.Module):
         return ws
 
     def _bf16_arena(self):
-        """16-bit shadow of the arena in the format of `self.precision` (bf16 or IEEE half), refreshed when the
-        fp32 master changes."""
-        if self.precision in (_lib.F32, _lib.F32X3):
+        """Shadow of the arena in the operand format of `self.precision`: bf16 / IEEE half (2 bytes per value) or, for
+        fp32x3, the pre-split (hi | lo halves) image with the fp32 arena's size and offsets.  Refreshed when the fp32
+        master changes."""
+        if self.precision == _lib.F32:
             return None
         ver = (self.arena._version, self.arena.data_ptr())
         if self._arena_bf16 is None or self._bf16_version != ver:
-            f16 = self.precision == _lib.F16
+            dt, cast = {_lib.BF16: (torch.bfloat16, _lib.lib().vitseg_cast_params_bf16),
+                        _lib.F16: (torch.float16, _lib.lib().vitseg_cast_params_f16),
+                        _lib.F32X3: (torch.float32, _lib.lib().vitseg_cast_params_split)}[self.precision]
             if self._arena_bf16 is None:
-                self._arena_bf16 = torch.empty(self.arena.numel(), dtype=torch.float16 if f16 else torch.bfloat16,
-                                               device=self.arena.device)
-            cast = _lib.lib().vitseg_cast_params_f16 if f16 else _lib.lib().vitseg_cast_params_bf16
+                self._arena_bf16 = torch.empty(self.arena.numel(), dtype=dt, device=self.arena.device)
             _lib.check(cast(self.arena.data_ptr(), self._arena_bf16.data_ptr(), self.arena.numel(),
                             torch.cuda.current_stream().cuda_stream))
             self._bf16_version = ver
