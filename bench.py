@@ -40,24 +40,24 @@ KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
             "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0, 0>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
             "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 0>",
             "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
-    "bf16": {"gemm_bias": "gemm_bf16_large_kernel<unsigned short, unsigned short, 0, 0, 256>",
-             "gemm_gelu": "gemm_bf16_large_kernel<unsigned short, unsigned short, 0, 1, 256>",
+    "bf16": {"gemm_bias": "gemm_bf16_large_kernel<unsigned short, unsigned short, 0, 0, 256, 8>",
+             "gemm_gelu": "gemm_bf16_large_kernel<unsigned short, unsigned short, 0, 1, 256, 8>",
              "gemm_resadd": "gemm_kernel<unsigned short, float, 0, 2, 0, 0, 0> (o_proj) + "
-                            "gemm_bf16_large_kernel<unsigned short, float, 0, 2, 128> (fc2)",
+                            "gemm_bf16_large_kernel<unsigned short, float, 0, 2, 128, 8> (fc2)",
              "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
-             "gemm_conv3": "gemm_bf16_large_kernel<unsigned short, float, 2, 3, 128>",
+             "gemm_conv3": "gemm_bf16_large_kernel<unsigned short, float, 2, 3, 128, 8>",
              "attention": "attn_bf16_kernel<false, unsigned short> + attn_cls_bf16_kernel<unsigned short>"},
-    "f32x3": {"gemm_bias": "gemm_kernel<float, float, 0, 0, 0, 0, 1>", "gemm_gelu": "gemm_kernel<float, float, 0, 1, 0, 0, 1>",
-              "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0, 1>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 1>",
-              "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 1>",
-              "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
+    "f32x3": {"gemm_bias": "gemm_kernel<float, float, 0, 0, 0, 0, 2>", "gemm_gelu": "gemm_kernel<float, float, 0, 1, 0, 0, 2>",
+              "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0, 2>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 2>",
+              "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 2>",
+              "attention": "attn_x3_kernel<false> + attn_cls_f32_kernel"},
     # rocprofv3's demangler does not know _Float16 (DF16_): the IEEE-half instantiations appear mangled in its CSVs
-    "f16": {"gemm_bias": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_DF16_Li0ELi0ELi256EEEvNS_8GemmArgsE",
-            "gemm_gelu": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_DF16_Li0ELi1ELi256EEEvNS_8GemmArgsE",
+    "f16": {"gemm_bias": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_DF16_Li0ELi0ELi256ELi8EEEvNS_8GemmArgsE",
+            "gemm_gelu": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_DF16_Li0ELi1ELi256ELi8EEEvNS_8GemmArgsE",
             "gemm_resadd": "_ZN6vitseg12_GLOBAL__N_111gemm_kernelIDF16_fLi0ELi2ELi0ELi0ELi0EEEvNS_8GemmArgsE (o_proj) + "
-                           "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi0ELi2ELi128EEEvNS_8GemmArgsE (fc2)",
+                           "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi0ELi2ELi128ELi8EEEvNS_8GemmArgsE (fc2)",
             "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
-            "gemm_conv3": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi2ELi3ELi128EEEvNS_8GemmArgsE",
+            "gemm_conv3": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi2ELi3ELi128ELi8EEEvNS_8GemmArgsE",
             "attention": "_ZN6vitseg12_GLOBAL__N_116attn_bf16_kernelILb0EDF16_EEvPKtPtPfiiiNS_8DropArgsE + "
                          "_ZN6vitseg12_GLOBAL__N_120attn_cls_bf16_kernelIDF16_EEvPKtPtPfiiiNS_8DropArgsE"},
 }
