@@ -64,18 +64,20 @@ def _post(url, fields, files, token=TOKEN):
         return e.code, json.loads(e.read() or b"{}")
 
 
-def _fake_slot(calls):
-    def predict_batch(images):   # "network": class = parity of the image's top-left red value, 8x8 masks
+def _fake_slot(calls, gate):
+    def predict_batch(images):   # "network": class = the image's top-left red value mod 3, 8x8 masks
         calls.append(len(images))
-        time.sleep(0.05)         # long enough for concurrent uploads to pile up behind the first batch
+        gate.wait(timeout=5.0)   # the first forward lasts until the test says every upload has been queued
         return [np.full((8, 8), int(a[0, 0, 0]) % 3, np.uint8) for a in images]
     return ModelSlot(predict_batch, 3)
 
 
 @pytest.fixture
 def service():
-    be, calls = FakeBackend(), []
-    w = Worker({7: _fake_slot(calls)}, be.url, TOKEN, max_batch=8, batch_wait_s=0.02)
+    be, calls, gate = FakeBackend(), [], threading.Event()
+    gate.set()
+    w = Worker({7: _fake_slot(calls, gate)}, be.url, TOKEN, max_batch=8, batch_wait_s=0.02)
+    w.gate = gate
     srv = w.serve("127.0.0.1", 0)
     threading.Thread(target=srv.serve_forever, daemon=True).start()
     yield w, be, f"http://127.0.0.1:{srv.server_address[1]}", calls
@@ -124,9 +126,12 @@ def test_concurrent_jobs_share_a_forward(service):
         img[0, 0, 0] = i
         assert _post(url + "/enqueue/", {"job_id": f"job{i}", "vision_model_id": "7"},
                      {"input_image": ("x.png", _png(img), "image/png")})[0] == 202
+    w.gate.clear()                                         # hold the first forward open ...
     ts = [threading.Thread(target=send, args=(i,)) for i in range(12)]
     [t.start() for t in ts]
     [t.join() for t in ts]
+    assert w.stats["received"] == 12
+    w.gate.set()                                           # ... until all 12 uploads sit in the queue
     for _ in range(300):
         if len(be.done) == 12:
             break
