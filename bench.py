@@ -459,7 +459,8 @@ def main():
                                  "bytes_per_launch": prof[k]["work"] / max(prof[k]["launches"], 1)}
                              for k in ("layernorm", "upsample") if prof[k]["ms"] > 0},
         }
-        if args.precision == "f32" and not args.no_cpu_baseline:
+        extras = not args.no_cpu_baseline and world == 1   # CPU baseline / side paths: N = 1 only (spec), rank 0
+        if args.precision == "f32" and extras:
             # informational (outside the timed region, rank 0 only): the same step on the other operand formats.
             # f32x3 = fp32 storage, GEMM operands split into half pairs, 3 fp16 MFMAs per product (fp32-grade results);
             # bf16 = bf16 operands / fp32 accumulate.  The timed `value` above is the exact-fp32 MFMA path.
@@ -483,7 +484,7 @@ def main():
                 if prec == "fp32x3":
                     lg_x3, mk_x3 = lg2, mk2
                 del m2
-        if not args.no_cpu_baseline:
+        if extras:
             base, parity, oracle_out = cpu_baseline(cfg, sd_np, images_np, logits, mask)
             out["cpu_baseline"] = base
             out["parity"] = parity

@@ -216,12 +216,15 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     // ---- embeddings (a2 + a3): patch GEMM gathers straight from the NCHW image ----
     {
         GemmArgs g{};
-        g.A = x; g.W = x3 == 2 ? WG(VITSEG_T_PATCH_W) : (const void*)W(VITSEG_T_PATCH_W); g.bias = W(VITSEG_T_PATCH_B); g.R = W(VITSEG_T_POS); g.C = X;
+        g.A = x; g.W = x3 == 2 ? WG(VITSEG_T_PATCH_W) : (const void*)W(VITSEG_T_PATCH_W);  // fp32 (or pre-split) weights
+        g.bias = W(VITSEG_T_PATCH_B); g.R = W(VITSEG_T_POS); g.C = X;
         g.M = Mp; g.N = D; g.K = s.Kp; g.lda = 0; g.ldc = D;
         g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
         {
             ProfScope ps(VITSEG_K_GEMM_PATCH, 2.0 * g.M * g.N * g.K, st);
-            if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st, x3))) return rc;
+            // 16-bit modes: the image and the patch weights are fp32 either way; the split-operand kernel (fp32-grade
+            // products on the fp16 pipe) does this GEMM in 0.16 ms instead of 0.36 ms
+            if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st, lp ? 1 : x3))) return rc;
         }
         if ((rc = launch_cls_rows(W(VITSEG_T_CLS), W(VITSEG_T_POS), X, batch, s.Np, D, st))) return rc;
     }

@@ -190,7 +190,7 @@ int forward_train_bf16(Ctx& c, const float* x, float* logits) {
         float* X0 = c.L(0, c.p.lb.xin);
         GemmArgs g = lin(x, c.W(VITSEG_T_PATCH_W), c.W(VITSEG_T_PATCH_B), c.W(VITSEG_T_POS), X0, Mp, D, s.Kp, 0, D);
         g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
-        if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st))) return rc;
+        if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st, 1))) return rc;
         if ((rc = launch_cls_rows(c.W(VITSEG_T_CLS), c.W(VITSEG_T_POS), X0, batch, s.Np, D, st))) return rc;
         if (c.drop_p > 0.f && (rc = launch_dropout_rows(X0, X0, 0, Mt, D, c.dr(0, 0), st))) return rc;
     }
