@@ -355,3 +355,28 @@ def test_dropout_bf16_consistent_with_fp32_same_masks():
         if b.norm() < 1e-6:
             continue
         assert float((a - b).norm() / b.norm()) < 0.2 and float((a @ b) / (a.norm() * b.norm())) > 0.98, k
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 1.2e-1)])   # bf16: the tiny CLS gradient is the noisiest
+def test_training_step_patch4_against_oracle_autograd(precision, tol):
+    """Patch size 4 (48-wide im2col, 64 tokens at 32x32) through forward + CE + backward against autograd on the
+    oracle: per-tensor relative L2 error of the gradients."""
+    from visiontransformer_amd.params import arena_views
+    cfg = ViTSegConfig(3, 4, 128, 1, 2, image_size=32)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=44).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 2, seed=4))
+    y = torch.from_numpy(synth.make_targets(cfg, 2, seed=4, size=32))
+    leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = O.ce_loss(O.forward(x.double(), leaf, cfg), y)
+    ref.backward()
+    m = ViTSegmentationModel(3, 4, 128, 1, 2, image_size=32, precision=precision, dropout=0.0, device=DEV).train()
+    m.load_state_dict(sd)
+    loss = m.ce_loss(x.to(DEV), y.to(DEV))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref)) < (1e-5 if precision == "fp32" else 5e-3)
+    gv = arena_views(cfg, m.arena.grad)
+    for k, r in leaf.items():
+        if r.grad is None or r.grad.norm().item() < 1e-6 or "pooler" in k:
+            continue
+        rel = (gv[k].cpu().double() - r.grad).norm().item() / r.grad.norm().item()
+        assert rel < tol, (k, rel)

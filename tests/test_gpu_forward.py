@@ -181,3 +181,27 @@ def test_vit_large_width_tiled_1024(precision, margin):
     with torch.no_grad():
         lg = m32(big[:, :, :512, :512].to(DEV))
         assert (lg.cpu() - O.forward(big[:, :, :512, :512], sd, cfg)).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("P,D,A", [(4, 512, 8), (8, 1024, 16), (16, 512, 8)])
+def test_reference_configuration_grid(P, D, A):
+    """The reference sweeps patch sizes 16 / 8 / 4 and widths 512 / 768 / 1024 (testViTModel.py:73-83).  The corners the
+    golden files do not hold -- P = 4 gives 3 137 tokens and a 48-wide patch GEMM -- against the oracle, in every
+    inference precision (2 layers, 224x224, one image)."""
+    cfg = ViTSegConfig(3, P, D, 2, A, image_size=224)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=P + D).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 1, seed=P))
+    with torch.no_grad():
+        ref = O.forward(x, sd, cfg)
+    ref_mask = O.predict_mask(ref)
+    srt = ref.sort(dim=1, descending=True).values
+    margin = srt[:, 0] - srt[:, 1]
+    for precision, tol in (("fp32", 2e-5), ("fp32x3", 2e-5), ("fp16", 2e-3), ("bf16", 3e-2)):
+        m = ViTSegmentationModel(3, P, D, 2, A, image_size=224, precision=precision, device=DEV).eval()
+        m.load_state_dict(sd)
+        with torch.no_grad():
+            mask, logits = m.predict_mask(x.to(DEV), return_logits=True)
+        err = (logits.cpu() - ref).abs().max().item()
+        assert err < tol, (precision, err)
+        solid = margin > 4 * tol
+        assert bool((mask.cpu().long() == ref_mask)[solid].all()), precision
