@@ -43,88 +43,108 @@ __device__ __forceinline__ void taps(int d, float scale, int n_in, int& i0, int&
     w0 = __fsub_rn(1.f, w1);
 }
 
+// Thread = a 4 (x) by UPR (y) block of output pixels: the x taps are computed once, and the two horizontally
+// interpolated source rows (`top`, `bot`) are reused while consecutive output rows keep the same source rows (at
+// 16x up-scaling 15 of 16 do; the test is wave-uniform because a wave covers one output row band).
+constexpr int UPR = 4;
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ Z, float* __restrict__ logits,
                                                        uint8_t* __restrict__ mask, int B, int C, int g, int S) {
-    const int quads = S >> 2;
+    const int quads = S >> 2, bands = S / UPR;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)B * S * quads) return;
+    if (idx >= (size_t)B * bands * quads) return;
     const int xq = (int)(idx % quads);
-    const int Y = (int)((idx / quads) % S);
-    const int b = (int)(idx / ((size_t)quads * S));
+    const int Y0 = (int)((idx / quads) % bands) * UPR;
+    const int b = (int)(idx / ((size_t)quads * bands));
     const float scale = (float)g / (float)S;
-    int y0, y1;
-    float wy0, wy1;
-    taps(Y, scale, g, y0, y1, wy0, wy1);
     int x0[4], x1[4];
     float wx0[4], wx1[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) taps(4 * xq + e, scale, g, x0[e], x1[e], wx0[e], wx1[e]);
+    int y0[UPR], y1[UPR];
+    float wy0[UPR], wy1[UPR];
+#pragma unroll
+    for (int r = 0; r < UPR; ++r) taps(Y0 + r, scale, g, y0[r], y1[r], wy0[r], wy1[r]);
 
     // argmax_c sigmoid(v_c) with first-index ties.  sigmoid is monotone, so the answer is the raw argmax m unless
-    // an EARLIER class rounds to the same fp32 sigmoid.  That cannot happen when the top-1 logit t1 has
-    // |t1| <= 8 and leads every other class by >= 4e-3: sigma' >= 3.3e-4 on [t1 - 4e-3, t1], so the true
-    // sigmoids differ by >= 1.3e-6 ~ 22 ulp(1), far beyond the <= 2 ulp error of 1/(1+exp(-x)).  Only the
-    // remaining (near-tie or saturated) pixels evaluate the exact fp32 sigmoids; the result is identical.
-    float t1[4], t2[4];
-    int arg[4];
+    // an EARLIER class rounds to the same fp32 sigmoid.  That cannot happen when the top-1 logit t1 leads every
+    // other class by a margin whose image under sigma is many ulps: |t1| <= 2 (sigma' >= 0.105) and margin >= 1e-4
+    // -> the true sigmoids differ by >= 1e-5 ~ 170 ulp(1); |t1| <= 8 (sigma' >= 3.3e-4) and margin >= 4e-3 ->
+    // >= 1.3e-6 ~ 22 ulp -- far beyond the <= 2 ulp error of 1/(1+exp(-x)).  Only the remaining (near-tie or
+    // saturated) pixels evaluate the exact fp32 sigmoids; the result is identical.
+    float t1[UPR][4], t2[UPR][4];
+    int arg[UPR][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        t1[e] = -INFINITY;
-        t2[e] = -INFINITY;
-        arg[e] = 0;
-    }
-    auto logit4 = [&](int c) {
-        const float* zt = Z + (((size_t)b * C + c) * g + y0) * g;
-        const float* zb = Z + (((size_t)b * C + c) * g + y1) * g;
-        f32x4 v;
+    for (int r = 0; r < UPR; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float top = __fmaf_rn(zt[x0[e]], wx0[e], __fmul_rn(zt[x1[e]], wx1[e]));
-            const float bot = __fmaf_rn(zb[x0[e]], wx0[e], __fmul_rn(zb[x1[e]], wx1[e]));
-            v[e] = __fmaf_rn(top, wy0, __fmul_rn(bot, wy1));
+            t1[r][e] = -INFINITY;
+            t2[r][e] = -INFINITY;
+            arg[r][e] = 0;
         }
+    auto hrow = [&](int c, int y) {  // source row y of class c interpolated along x at this thread's 4 columns
+        const float* z = Z + (((size_t)b * C + c) * g + y) * g;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __fmaf_rn(z[x0[e]], wx0[e], __fmul_rn(z[x1[e]], wx1[e]));
         return v;
     };
     for (int c = 0; c < C; ++c) {
-        const f32x4 v = logit4(c);
-        if (logits) *(f32x4*)(logits + (((size_t)b * C + c) * S + Y) * S + 4 * xq) = v;
-        if (mask) {
+        f32x4 top = hrow(c, y0[0]), bot = hrow(c, y1[0]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (v[e] > t1[e]) {  // strict: the first maximal class stays
-                    t2[e] = t1[e];
-                    t1[e] = v[e];
-                    arg[e] = c;
-                } else {
-                    t2[e] = fmaxf(t2[e], v[e]);
+        for (int r = 0; r < UPR; ++r) {
+            if (r > 0) {
+                if (y0[r] != y0[r - 1]) top = (y0[r] == y1[r - 1]) ? bot : hrow(c, y0[r]);
+                if (y1[r] != y1[r - 1]) bot = hrow(c, y1[r]);
+            }
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __fmaf_rn(top[e], wy0[r], __fmul_rn(bot[e], wy1[r]));
+            if (logits) *(f32x4*)(logits + (((size_t)b * C + c) * S + Y0 + r) * S + 4 * xq) = v;
+            if (mask) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (v[e] > t1[r][e]) {  // strict: the first maximal class stays
+                        t2[r][e] = t1[r][e];
+                        t1[r][e] = v[e];
+                        arg[r][e] = c;
+                    } else {
+                        t2[r][e] = fmaxf(t2[r][e], v[e]);
+                    }
                 }
             }
         }
     }
     if (mask) {
-        bool amb = false;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) amb = amb || !(fabsf(t1[e]) <= 8.0f && t1[e] - t2[e] >= 4e-3f);
-        if (amb) {  // exact path: torch CPU sigmoid 1 / (1 + exp(-x)), first maximal class wins
-            float best[4];
-            for (int c = 0; c < C; ++c) {
-                const f32x4 v = logit4(c);
+        for (int r = 0; r < UPR; ++r) {
+            bool amb = false;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float sg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v[e])));
-                    if (c == 0 || sg > best[e]) {
-                        best[e] = sg;
-                        arg[e] = c;
+            for (int e = 0; e < 4; ++e) {
+                const float at = fabsf(t1[r][e]), margin = t1[r][e] - t2[r][e];
+                amb = amb || !((at <= 2.0f && margin >= 1e-4f) || (at <= 8.0f && margin >= 4e-3f));
+            }
+            if (amb) {  // exact path: torch CPU sigmoid 1 / (1 + exp(-x)), first maximal class wins
+                float best[4];
+                for (int c = 0; c < C; ++c) {
+                    const f32x4 top = hrow(c, y0[r]), bot = hrow(c, y1[r]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = __fmaf_rn(top[e], wy0[r], __fmul_rn(bot[e], wy1[r]));
+                        const float sg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v)));
+                        if (c == 0 || sg > best[e]) {
+                            best[e] = sg;
+                            arg[r][e] = c;
+                        }
                     }
                 }
             }
+            uchar4 m4;
+            m4.x = (unsigned char)arg[r][0];
+            m4.y = (unsigned char)arg[r][1];
+            m4.z = (unsigned char)arg[r][2];
+            m4.w = (unsigned char)arg[r][3];
+            *(uchar4*)(mask + ((size_t)b * S + Y0 + r) * S + 4 * xq) = m4;
         }
-        uchar4 m4;
-        m4.x = (unsigned char)arg[0];
-        m4.y = (unsigned char)arg[1];
-        m4.z = (unsigned char)arg[2];
-        m4.w = (unsigned char)arg[3];
-        *(uchar4*)(mask + ((size_t)b * S + Y) * S + 4 * xq) = m4;
     }
 }
 
@@ -226,7 +246,7 @@ int launch_head1x1(const float* F, const float* W2, const float* b2, float* Z, i
 int launch_upsample(const float* Z, float* logits, uint8_t* mask, int B, int C, int g, int S, hipStream_t s) {
     VITSEG_CHECK_ARG(Z && (logits || mask), VITSEG_EINVAL, "upsample: null pointer");
     VITSEG_CHECK_ARG(S % 4 == 0 && C >= 1 && C <= 255, VITSEG_ESHAPE, "upsample: S %% 4 != 0 or C out of range");
-    const size_t n = (size_t)B * S * (S / 4);
+    const size_t n = (size_t)B * (S / UPR) * (S / 4);
     hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Z, logits, mask, B, C, g,
                        S);
     VITSEG_LAUNCH_CHECK("upsample");
