@@ -589,7 +589,127 @@ int launch_one(GemmArgs a, hipStream_t s) {
 
 }  // namespace
 
-int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s, int x3) {
+namespace {
+
+// out[r][c4] = epi(sum_s partial[s][r][c4] + bias): the K slices of the CLS rows, summed in slice order (deterministic)
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(256) void thin_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                          const float* __restrict__ R, OutT* __restrict__ C, int rows, int N,
+                                                          int ldc, int splits) {
+    const int n4 = N >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * n4) return;
+    const int r = i / n4, c = (i - r * n4) * 4;
+    const size_t slab = (size_t)rows * N;
+    f32x4 acc = *(const f32x4*)(partial + (size_t)r * N + c);
+    for (int sIdx = 1; sIdx < splits; ++sIdx) {
+        const f32x4 v = *(const f32x4*)(partial + sIdx * slab + (size_t)r * N + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b4 = *(const f32x4*)(bias + c);
+    f32x4 res = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_RESADD) res = *(const f32x4*)(R + (size_t)r * ldc + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = acc[e] + b4[e];
+        if (EPI == EPI_GELU) x = sizeof(OutT) == 4 ? gelu_erf(x) : gelu_erf_fast(x);  // as the tile kernels of that format
+        if (EPI == EPI_RESADD) x = res[e] + x;
+        acc[e] = x;
+    }
+    if constexpr (sizeof(OutT) == 4) {
+        *(f32x4*)(C + (size_t)r * ldc + c) = acc;
+    } else {
+        uint2 h;
+        h.x = H16<OutT>::pack2(acc[0], acc[1]);
+        h.y = H16<OutT>::pack2(acc[2], acc[3]);
+        *(uint2*)(C + (size_t)r * ldc + c) = h;
+    }
+}
+
+template <typename OutT>
+int launch_thin_reduce(const GemmArgs& a, int epi, int splits, hipStream_t s) {
+    const int rows = a.thin_rows, body = a.M - rows;
+    const int blocks = (rows * (a.N / 4) + 255) / 256;
+    const float* R = a.R ? a.R + (size_t)body * a.ldc : nullptr;
+    OutT* C = (OutT*)a.C + (size_t)body * a.ldc;
+    switch (epi) {
+        case EPI_BIAS:
+            hipLaunchKernelGGL((thin_reduce_kernel<EPI_BIAS, OutT>), dim3(blocks), dim3(256), 0, s, a.thin_scratch, a.bias, R, C,
+                               rows, a.N, a.ldc, splits);
+            break;
+        case EPI_GELU:
+            hipLaunchKernelGGL((thin_reduce_kernel<EPI_GELU, OutT>), dim3(blocks), dim3(256), 0, s, a.thin_scratch, a.bias, R, C,
+                               rows, a.N, a.ldc, splits);
+            break;
+        default:
+            hipLaunchKernelGGL((thin_reduce_kernel<EPI_RESADD, OutT>), dim3(blocks), dim3(256), 0, s, a.thin_scratch, a.bias, R,
+                               C, rows, a.N, a.ldc, splits);
+    }
+    VITSEG_LAUNCH_CHECK("thin_reduce");
+    return VITSEG_OK;
+}
+
+// true when the trailing rows of `a` should go through the split-K side launch (see GemmArgs::thin_scratch)
+bool thin_split_applies(const GemmArgs& a, int epi) {
+    return a.thin_scratch && a.thin_rows > 0 && a.thin_rows <= THIN_MAX_ROWS && a.M > a.thin_rows &&
+           (a.M - a.thin_rows) % BM == 0 && a.K >= 256 && a.K % 32 == 0 && !a.drop.thresh && !a.aux && a.splitk <= 1 &&
+           a.ldc % 4 == 0 && (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESADD);
+}
+
+template <int X3>
+int launch_thin_rows(const GemmArgs& a, int epi, hipStream_t s) {
+    const int rows = a.thin_rows, body = a.M - rows;
+    int splits = a.K / 32 / 4;  // >= 4 K steps per slice
+    if (splits > THIN_MAX_SPLITS) splits = THIN_MAX_SPLITS;
+    GemmArgs t = a;
+    t.A = (const float*)a.A + (size_t)body * a.lda;
+    t.M = rows;
+    t.bias = nullptr;
+    t.R = nullptr;
+    t.C = a.thin_scratch;
+    t.ldc = a.N;
+    t.splitk = splits;
+    t.split_stride = (size_t)rows * a.N;
+    t.thin_scratch = nullptr;
+    if (int rc = launch_one<float, float, A_PLAIN, EPI_BIAS, 0, 0, X3>(t, s)) return rc;
+    return launch_thin_reduce<float>(a, epi, splits, s);
+}
+
+// 16-bit operands: K slices of 64-element steps, fp32 partials, output in the consumer's format
+template <typename T>
+int launch_thin_rows_h16(const GemmArgs& a, int epi, hipStream_t s) {
+    const int rows = a.thin_rows, body = a.M - rows;
+    int splits = a.K / 64 / 4;
+    if (splits > THIN_MAX_SPLITS) splits = THIN_MAX_SPLITS;
+    if (splits < 1) splits = 1;
+    GemmArgs t = a;
+    t.A = (const T*)a.A + (size_t)body * a.lda;
+    t.M = rows;
+    t.bias = nullptr;
+    t.R = nullptr;
+    t.C = a.thin_scratch;
+    t.ldc = a.N;
+    t.splitk = splits;
+    t.split_stride = (size_t)rows * a.N;
+    t.thin_scratch = nullptr;
+    if (int rc = launch_one<T, float, A_PLAIN, EPI_BIAS>(t, s)) return rc;
+    return epi == EPI_RESADD ? launch_thin_reduce<float>(a, epi, splits, s) : launch_thin_reduce<T>(a, epi, splits, s);
+}
+
+}  // namespace
+
+int launch_gemm_f32(const GemmArgs& a_in, int amode, int epi, hipStream_t s, int x3) {
+    GemmArgs a = a_in;
+    if (amode == A_PLAIN && thin_split_applies(a_in, epi)) {
+        // the CLS rows first (tiny, split over K), then the whole-tile body: an exact number of rounds of blocks
+        if (int rc = x3 == 2 ? launch_thin_rows<2>(a_in, epi, s) : x3 == 1 ? launch_thin_rows<1>(a_in, epi, s)
+                                                                           : launch_thin_rows<0>(a_in, epi, s))
+            return rc;
+        a.M = a_in.M - a_in.thin_rows;
+    }
+    a.thin_scratch = nullptr;
     VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 4 == 0, VITSEG_EINVAL, "gemm_f32: bad M/N/K %d %d %d", a.M,
                      a.N, a.K);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm: N=%d and ldc=%d must be multiples of 4", a.N,
@@ -992,7 +1112,13 @@ int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, h
 // bf16 operands (A and W), fp32 accumulate.  Output type follows the consumer: bf16 for tensors
 // that feed the next MFMA (q|k|v, MLP hidden), fp32 for the residual stream and the head features.
 template <typename T>
-int launch_gemm_h16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
+int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
+    GemmArgs a = a_in;
+    if (amode == A_PLAIN && thin_split_applies(a_in, epi) && (a_in.M - a_in.thin_rows) % LBM == 0 && a_in.K % 64 == 0) {
+        if (int rc = launch_thin_rows_h16<T>(a_in, epi, s)) return rc;  // CLS rows: split-K side launch (GemmArgs)
+        a.M = a_in.M - a_in.thin_rows;
+    }
+    a.thin_scratch = nullptr;
     VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, VITSEG_EINVAL, "gemm_bf16: bad M/N/K %d %d %d", a.M, a.N, a.K);
     VITSEG_CHECK_ARG(a.K % 64 == 0, VITSEG_ESHAPE, "gemm_bf16: K=%d must be a multiple of 64", a.K);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm: N=%d and ldc=%d must be multiples of 4", a.N,

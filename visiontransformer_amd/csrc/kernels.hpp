@@ -36,11 +36,19 @@ struct GemmArgs {
     const void* zeros;  // >= 128 zero bytes (bf16 A_CONV3: source of the padding taps)
     int splitk;           // > 1: grid.y slices of the K range, each writing C + y * split_stride
     size_t split_stride;
+    // CLS rows by split-K (fp32 / x3 forward, A_PLAIN): when the last `thin_rows` rows (<= 64) follow a whole number of
+    // 128-row tiles and the GEMM has few column tiles, they are computed by a second launch cut into K slices (partials in
+    // `thin_scratch`, >= thin_scratch_floats(N) floats) and a fixed-order reduce + epilogue, instead of one extra
+    // quarter-cost tile per column that prolongs the whole launch by a partial round.
+    float* thin_scratch;
+    int thin_rows;
     int gn;               // column-group width of the tile order (0 = pick from K; VITSEG_GN overrides for experiments)
     DropArgs drop;        // EPI_RESADD: C = R + dropout(acc + bias)   (hidden dropout, modeling_vit.py:276,283)
 };
 
 // x3: fp32 operands split into half pairs while staged, 3 fp16 MFMAs per product (fp32-grade results, gemm.hip X3)
+constexpr int THIN_MAX_SPLITS = 16, THIN_MAX_ROWS = 64;
+inline size_t thin_scratch_floats(int max_n) { return (size_t)THIN_MAX_SPLITS * THIN_MAX_ROWS * max_n; }
 int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s, int x3 = 0);  // 1: split A and W, 2: W pre-split
 int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, hipStream_t s);
 size_t wgrad_scratch_floats(int M, int N, int K);

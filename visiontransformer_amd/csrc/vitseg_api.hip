@@ -31,7 +31,7 @@ using namespace plan;
 
 // ---- workspace plan -------------------------------------------------------------
 struct Plan {
-    size_t zero, x, h, qkv, u, f, z, total;  // byte offsets
+    size_t zero, x, h, qkv, u, f, z, thin, total;  // byte offsets
     size_t Mt, Mp;                     // total token rows, patch rows
 };
 
@@ -53,6 +53,8 @@ Plan make_plan(const Shape& s, int B, int precision) {
     p.u = take(p.Mt * (size_t)s.I * act);             // MLP hidden
     p.f = take(p.Mp * MID * 4);                       // seg_head.0 output (fp32)
     p.z = take((size_t)B * s.C * s.Np * 4);           // low-res logits
+    const int widest = 3 * s.D > s.I ? 3 * s.D : s.I;
+    p.thin = take(thin_scratch_floats(widest) * 4);   // K-slice partials of the CLS rows (GemmArgs::thin_scratch)
     p.total = off;
     return p;
 }
@@ -230,8 +232,13 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
     }
     // ---- encoder layers (a4..a8) ----
     const double ln_bytes = 2.0 * Mt * D * 4;
-    auto gemm = [&](const GemmArgs& g, int epi, int kind) {
+    // when the patch rows are a whole number of row tiles, the trailing CLS rows of the linear layers go
+    // through the split-K side launch (bitwise batch-invariant: a CLS row takes that path at every batch size)
+    const int thin_rows = (p.Mp % 256 == 0 && batch <= THIN_MAX_ROWS) ? batch : 0;
+    auto gemm = [&](GemmArgs g, int epi, int kind) {
         ProfScope ps(kind, 2.0 * g.M * g.N * g.K, st);
+        g.thin_rows = thin_rows;
+        g.thin_scratch = (float*)(ws + p.thin);
         return lp ? launch_gemm_bf16(g, A_PLAIN, epi, st, f16) : launch_gemm_f32(g, A_PLAIN, epi, st, x3);
     };
     auto lnorm = [&](const float* w, const float* b, int rows) {
