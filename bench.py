@@ -335,6 +335,11 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
                                    f"512x512, {args.precision}, dropout {model.dropout} (reference: 0.1)", "batch_per_gpu": B,
                        "global_batch": B * world,
                        "parallelism": f"data-parallel x{world}, bucketed gradient all-reduce (RCCL) overlapped with the backward"},
+            # the step is ~100 MFMA kernel kinds; the roofline here is the whole step's algorithmic FLOPs (3 x forward)
+            # over its wall time, per-kernel times are in profiles/r01_bench_train_*_kernel_stats.csv
+            "roofline": {"bound": "mfma", "achieved": round(value / world * flops_img / 1e12, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(value / world * flops_img / 1e12 / peak, 4), "traffic": None,
+                         "kernel": "whole training step (forward + CE + backward + Adam)"},
             "whole_model": {"flops_per_image": flops_img,
                             "achieved_tflops_per_gpu": round(value / world * flops_img / 1e12, 2),
                             "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},
