@@ -91,7 +91,8 @@ enum vitseg_precision {
     VITSEG_F16 = 2,  /* IEEE-half operands, otherwise as VITSEG_BF16; inference only (BASELINE configs[4]) */
     VITSEG_F32X3 = 3 /* fp32 storage everywhere; GEMM operands split into (hi, lo) half pairs while staged and multiplied
                         with 3 fp16 MFMAs per product (22-bit operand significands, fp32 accumulate); attention,
-                        LayerNorm, softmax as VITSEG_F32.  Inference only. */
+                        LayerNorm, softmax as VITSEG_F32.  Inference only.  Domain: GEMM / attention operand values
+                        must lie inside the half range (|x| < 65504), larger ones become inf and surface as NaN. */
 };
 
 /* Workspace buffers whose contents are defined after vitseg_forward returns
