@@ -232,3 +232,27 @@ def test_cls_split_k_path_parity_and_batch_invariance(precision):
         O.forward(x[:1].double(), {k: v.double() for k, v in sd.items()}, cfg, stages)
     cls_ref = stages[f"layer_{cfg.num_hidden_layers - 1}"][0, 0]
     assert (tok[cfg.num_patches].cpu().double() - cls_ref).abs().max().item() < (2e-5 if precision != "bf16" else 6e-2)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graph_replay_equals_eager(precision):
+    """predict_mask_graphed: the forward captured as a hipGraph gives the same bits as the eager launch sequence, for
+    fresh inputs, interleaved batch sizes, and after a parameter update (re-capture)."""
+    g = Golden("tiny16_224_c2")
+    m = build(g, precision=precision)
+    x = g.images().to(DEV)
+    with torch.no_grad():
+        ref_mask, ref_logits = m.predict_mask(x, return_logits=True)
+        ref1 = m.predict_mask(x[:1])
+    mk, lg = m.predict_mask_graphed(x, return_logits=True)
+    assert torch.equal(mk, ref_mask) and torch.equal(lg, ref_logits)
+    assert torch.equal(m.predict_mask_graphed(x[:1]), ref1)                 # another batch size, its own graph
+    x2 = torch.flip(x, dims=[3])
+    with torch.no_grad():
+        ref2 = m.predict_mask(x2)
+    assert torch.equal(m.predict_mask_graphed(x2, return_logits=True)[0], ref2)   # replay with new data
+    assert torch.equal(m.predict_mask_graphed(x[:1]), ref1)
+    with torch.no_grad():
+        m.arena.mul_(1.01)                                                  # parameters change -> re-capture
+        ref3 = m.predict_mask(x)
+    assert torch.equal(m.predict_mask_graphed(x, return_logits=True)[0], ref3)

@@ -77,6 +77,7 @@ class ViTSegmentationModel(nn.Module):
         self.grad_bucket_mb = 48.0
         self._buckets = None
         self._grads_reduced = False
+        self._graphs = {}   # (batch, with logits) -> captured hipGraph of the forward (predict_mask_graphed)
         n = _lib.param_count(self.cfg)  # validates the configuration (ValueError on unsupported shapes)
         self.arena = nn.Parameter(torch.zeros(n, dtype=torch.float32, device=device))
         self._views: Optional[Dict[str, torch.Tensor]] = None
@@ -195,13 +196,14 @@ class ViTSegmentationModel(nn.Module):
             self._bf16_version = ver
         return self._arena_bf16
 
-    def _run(self, x: torch.Tensor, want_logits: bool, want_mask: bool):
+    def _run(self, x: torch.Tensor, want_logits: bool, want_mask: bool, ws: Optional[torch.Tensor] = None):
         self._check_input(x)
         x = x.to(torch.float32).contiguous()  # modeling_vit.py:369-371 casts to the weight dtype
         B, S, Cc = x.shape[0], self.cfg.image_size, self.cfg.num_classes
         logits = torch.empty((B, Cc, S, S), dtype=torch.float32, device=x.device) if want_logits else None
         mask = torch.empty((B, S, S), dtype=torch.uint8, device=x.device) if want_mask else None
-        ws = self.workspace(B)
+        if ws is None:
+            ws = self.workspace(B)
         lp = self._bf16_arena()
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream().cuda_stream
@@ -305,6 +307,38 @@ class ViTSegmentationModel(nn.Module):
         `logits.sigmoid()` + `argmax` (model/CE/testViTModel.py:122-126), fused into the decoder tail."""
         logits, mask = self._run(x, return_logits, True)
         return (mask, logits) if return_logits else mask
+
+    @torch.no_grad()
+    def predict_mask_graphed(self, x: torch.Tensor, return_logits: bool = False):
+        """`predict_mask` replayed from a captured hipGraph (one per batch size and output set): the ~110 kernel
+        launches of a forward become one graph launch.  Measured (tools/latency_probe.py, ViT-B/16): no gain at batch
+        1-8 -- 1.4 ms (bf16) to 5.9 ms (fp32) per forward at 224x224 is GPU time of under-filled GEMM launches, not host
+        launch time -- so nothing uses it by default; it is there for smaller models / faster hosts, and bit-identical
+        to the eager path.  Inputs are copied into the graph's static buffer; the returned tensors are the graph's
+        static outputs and are overwritten by the next call with the same batch size (clone them to keep them).
+        Re-captured automatically when the parameters change."""
+        self._check_input(x)
+        key = (int(x.shape[0]), bool(return_logits))
+        ver = (self.arena._version, self.arena.data_ptr())
+        g = self._graphs.get(key)
+        if g is None or g["ver"] != ver:
+            xs = x.to(torch.float32).contiguous().clone()
+            ws = torch.empty(_lib.query_workspace(self.cfg, key[0], self.precision), dtype=torch.uint8,
+                             device=self.arena.device)   # owned by the graph: `workspace()` recycles its buffer
+            side = torch.cuda.Stream(device=xs.device)
+            side.wait_stream(torch.cuda.current_stream(xs.device))
+            with torch.cuda.stream(side):            # warm-up outside the capture: workspace, shadow arena, attributes
+                for _ in range(2):
+                    self._run(xs, return_logits, True, ws)
+            torch.cuda.current_stream(xs.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                logits, mask = self._run(xs, return_logits, True, ws)
+            g = dict(graph=graph, x=xs, ws=ws, logits=logits, mask=mask, ver=ver)
+            self._graphs[key] = g
+        g["x"].copy_(x, non_blocking=True)
+        g["graph"].replay()
+        return (g["mask"], g["logits"]) if return_logits else g["mask"]
 
     @torch.no_grad()
     def predict_mask_tiled(self, x: torch.Tensor) -> torch.Tensor:
