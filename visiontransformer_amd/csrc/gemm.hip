@@ -652,6 +652,14 @@ int launch_thin_reduce(const GemmArgs& a, int epi, int splits, hipStream_t s) {
 }
 
 // true when the trailing rows of `a` should go through the split-K side launch (see GemmArgs::thin_scratch)
+// > 0: the whole (small) GEMM goes through K slices + the reducing epilogue kernel (kernels.hpp whole_split)
+int whole_split_applies(const GemmArgs& a, int epi, int kstep) {
+    const int sp = whole_split(a.M, a.N, a.K, kstep);
+    const bool ok = sp && a.thin_scratch && (size_t)sp * a.M * a.N <= a.thin_capacity && a.K % kstep == 0 && !a.drop.thresh &&
+                    !a.aux && a.splitk <= 1 && a.ldc % 4 == 0 && (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESADD);
+    return ok ? sp : 0;
+}
+
 bool thin_split_applies(const GemmArgs& a, int epi) {
     return a.thin_scratch && a.thin_rows > 0 && a.thin_rows <= THIN_MAX_ROWS && a.M > a.thin_rows &&
            (a.M - a.thin_rows) % BM == 0 && a.K >= 256 && a.K % 32 == 0 && !a.drop.thresh && !a.aux && a.splitk <= 1 &&
@@ -659,10 +667,12 @@ bool thin_split_applies(const GemmArgs& a, int epi) {
 }
 
 template <int X3>
-int launch_thin_rows(const GemmArgs& a, int epi, hipStream_t s) {
+int launch_thin_rows(const GemmArgs& a, int epi, hipStream_t s, int splits = 0) {
     const int rows = a.thin_rows, body = a.M - rows;
-    int splits = a.K / 32 / 4;  // >= 4 K steps per slice
-    if (splits > THIN_MAX_SPLITS) splits = THIN_MAX_SPLITS;
+    if (!splits) {
+        splits = a.K / 32 / 4;  // >= 4 K steps per slice
+        if (splits > THIN_MAX_SPLITS) splits = THIN_MAX_SPLITS;
+    }
     GemmArgs t = a;
     t.A = (const float*)a.A + (size_t)body * a.lda;
     t.M = rows;
@@ -679,11 +689,13 @@ int launch_thin_rows(const GemmArgs& a, int epi, hipStream_t s) {
 
 // 16-bit operands: K slices of 64-element steps, fp32 partials, output in the consumer's format
 template <typename T>
-int launch_thin_rows_h16(const GemmArgs& a, int epi, hipStream_t s) {
+int launch_thin_rows_h16(const GemmArgs& a, int epi, hipStream_t s, int splits = 0) {
     const int rows = a.thin_rows, body = a.M - rows;
-    int splits = a.K / 64 / 4;
-    if (splits > THIN_MAX_SPLITS) splits = THIN_MAX_SPLITS;
-    if (splits < 1) splits = 1;
+    if (!splits) {
+        splits = a.K / 64 / 4;
+        if (splits > THIN_MAX_SPLITS) splits = THIN_MAX_SPLITS;
+        if (splits < 1) splits = 1;
+    }
     GemmArgs t = a;
     t.A = (const T*)a.A + (size_t)body * a.lda;
     t.M = rows;
@@ -702,6 +714,14 @@ int launch_thin_rows_h16(const GemmArgs& a, int epi, hipStream_t s) {
 
 int launch_gemm_f32(const GemmArgs& a_in, int amode, int epi, hipStream_t s, int x3) {
     GemmArgs a = a_in;
+    if (amode == A_PLAIN) {
+        if (const int sp = whole_split_applies(a_in, epi, 32)) {  // small batch: every row through K slices
+            GemmArgs w = a_in;
+            w.thin_rows = a_in.M;
+            return x3 == 2 ? launch_thin_rows<2>(w, epi, s, sp) : x3 == 1 ? launch_thin_rows<1>(w, epi, s, sp)
+                                                                        : launch_thin_rows<0>(w, epi, s, sp);
+        }
+    }
     if (amode == A_PLAIN && thin_split_applies(a_in, epi)) {
         // the CLS rows first (tiny, split over K), then the whole-tile body: an exact number of rounds of blocks
         if (int rc = x3 == 2 ? launch_thin_rows<2>(a_in, epi, s) : x3 == 1 ? launch_thin_rows<1>(a_in, epi, s)
@@ -1114,6 +1134,13 @@ int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, h
 template <typename T>
 int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
     GemmArgs a = a_in;
+    if (amode == A_PLAIN) {
+        if (const int sp = whole_split_applies(a_in, epi, 64)) {  // small batch: every row through K slices
+            GemmArgs w = a_in;
+            w.thin_rows = a_in.M;
+            return launch_thin_rows_h16<T>(w, epi, s, sp);
+        }
+    }
     if (amode == A_PLAIN && thin_split_applies(a_in, epi) && (a_in.M - a_in.thin_rows) % LBM == 0 && a_in.K % 64 == 0) {
         if (int rc = launch_thin_rows_h16<T>(a_in, epi, s)) return rc;  // CLS rows: split-K side launch (GemmArgs)
         a.M = a_in.M - a_in.thin_rows;

@@ -41,6 +41,7 @@ struct GemmArgs {
     // `thin_scratch`, >= thin_scratch_floats(N) floats) and a fixed-order reduce + epilogue, instead of one extra
     // quarter-cost tile per column that prolongs the whole launch by a partial round.
     float* thin_scratch;
+    size_t thin_capacity;  // floats available in thin_scratch
     int thin_rows;
     int gn;               // column-group width of the tile order (0 = pick from K; VITSEG_GN overrides for experiments)
     DropArgs drop;        // EPI_RESADD: C = R + dropout(acc + bias)   (hidden dropout, modeling_vit.py:276,283)
@@ -49,6 +50,16 @@ struct GemmArgs {
 // x3: fp32 operands split into half pairs while staged, 3 fp16 MFMAs per product (fp32-grade results, gemm.hip X3)
 constexpr int THIN_MAX_SPLITS = 16, THIN_MAX_ROWS = 64;
 inline size_t thin_scratch_floats(int max_n) { return (size_t)THIN_MAX_SPLITS * THIN_MAX_ROWS * max_n; }
+// Small batches: a GEMM with at most 128 output tiles leaves most of the 512 block slots idle while each tile walks its whole K
+// range (a ViT-B/16 forward of ONE 224x224 image took 5.9 ms in fp32).  Such a GEMM is cut into K slices as a whole:
+// returns the slice count (0 = do not split); kstep = elements per staged K step (32 fp32, 64 for 16-bit operands).
+inline int whole_split(int M, int N, int K, int kstep) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles > 128 || K < 512) return 0;
+    int s = K / kstep / 4;
+    if (s > 8) s = 8;
+    return s >= 2 ? s : 0;
+}
 int launch_gemm_f32(const GemmArgs& a, int amode, int epi, hipStream_t s, int x3 = 0);  // 1: split A and W, 2: W pre-split
 int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, hipStream_t s);
 size_t wgrad_scratch_floats(int M, int N, int K);

@@ -32,6 +32,7 @@ using namespace plan;
 // ---- workspace plan -------------------------------------------------------------
 struct Plan {
     size_t zero, x, h, qkv, u, f, z, thin, total;  // byte offsets
+    size_t thin_floats;                // capacity of the split-K scratch
     size_t Mt, Mp;                     // total token rows, patch rows
 };
 
@@ -54,7 +55,13 @@ Plan make_plan(const Shape& s, int B, int precision) {
     p.f = take(p.Mp * MID * 4);                       // seg_head.0 output (fp32)
     p.z = take((size_t)B * s.C * s.Np * 4);           // low-res logits
     const int widest = 3 * s.D > s.I ? 3 * s.D : s.I;
-    p.thin = take(thin_scratch_floats(widest) * 4);   // K-slice partials of the CLS rows (GemmArgs::thin_scratch)
+    p.thin_floats = thin_scratch_floats(widest);      // K-slice partials: CLS rows (GemmArgs::thin_scratch) ...
+    const int shapes[4][2] = {{3 * s.D, s.D}, {s.D, s.D}, {s.I, s.D}, {s.D, s.I}};   // ... or whole small GEMMs (N, K)
+    for (auto& nk : shapes) {
+        const size_t need = (size_t)whole_split((int)p.Mt, nk[0], nk[1], 32) * p.Mt * nk[0];
+        if (need > p.thin_floats) p.thin_floats = need;
+    }
+    p.thin = take(p.thin_floats * 4);
     p.total = off;
     return p;
 }
@@ -239,6 +246,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         ProfScope ps(kind, 2.0 * g.M * g.N * g.K, st);
         g.thin_rows = thin_rows;
         g.thin_scratch = (float*)(ws + p.thin);
+        g.thin_capacity = p.thin_floats;
         return lp ? launch_gemm_bf16(g, A_PLAIN, epi, st, f16) : launch_gemm_f32(g, A_PLAIN, epi, st, x3);
     };
     auto lnorm = [&](const float* w, const float* b, int rows) {
