@@ -19,13 +19,15 @@ class Masks:
     def __init__(self, p, seed64, B, Np, A):
         self.p, self.B, self.Np, self.A = p, B, Np, A
         self.seed = np.uint32((seed64 ^ (seed64 >> 32)) & 0xFFFFFFFF)
-        self.thresh = np.uint32(int(p * 4294967296.0))
+        self.thresh = np.uint32(max(1, int(p * 65536.0 + 0.5)))
         self.scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
 
     def _keep(self, stream, major, minor):
         with np.errstate(over="ignore"):
             key = fmix32(self.seed ^ (np.uint32(stream) * np.uint32(0x9E3779B1)) ^ (major.astype(np.uint32) * np.uint32(0x85EBCA77)))
-            return fmix32(minor.astype(np.uint32) ^ key) >= self.thresh
+            m = minor.astype(np.uint32)
+            h = fmix32((m >> np.uint32(1)) ^ key)
+            return np.where(m & np.uint32(1), h >> np.uint32(16), h & np.uint32(0xFFFF)) >= self.thresh
 
     def _gen(self, n_ref):  # reference token index (CLS first) -> generic index (CLS last)
         return np.where(n_ref == 0, self.Np, n_ref - 1)

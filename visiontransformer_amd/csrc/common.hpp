@@ -58,7 +58,8 @@ __device__ __forceinline__ AttnTile attn_tile(int ntiles, int A) {
 }
 
 // ---- dropout: counter-based keep/drop decision (no state, identical in forward and backward) ----
-// keep(seed, stream, major, minor) = fmix32(minor ^ fmix32(seed ^ stream*C1 ^ major*C2)) >= thresh, thresh = p * 2^32.
+// keep(seed, stream, major, minor) = half[minor & 1](fmix32((minor >> 1) ^ fmix32(seed ^ stream*C1 ^ major*C2))) >= thresh,
+// thresh = round(p * 2^16): the low / high 16 bits of one hash serve the even / odd element of a pair.
 // `stream` = layer * 8 + site (0 embeddings, 1 attention probabilities, 2 attention output, 3 MLP output);
 // (major, minor) = (row, column) of the tensor, or (bh * N + query, key) for attention probabilities.
 // The same function is restated in numpy by the tests (tests/dropout_ref.py) to inject identical masks
@@ -74,11 +75,15 @@ __host__ __device__ __forceinline__ unsigned fmix32(unsigned h) {
 __host__ __device__ __forceinline__ unsigned drop_key(unsigned seed, unsigned stream, unsigned major) {
     return fmix32(seed ^ (stream * 0x9E3779B1u) ^ (major * 0x85EBCA77u));
 }
+// One hash decides TWO neighbouring elements (minor = 2j, 2j + 1): 16 bits each against thresh = round(p * 2^16).
+// The kernels ask for the elements of a pair back to back, so the compiler keeps one fmix32 per pair -- hashing the
+// N x N attention probabilities three times per layer (forward + the two backward kernels) was 8 % of a training step.
 __host__ __device__ __forceinline__ bool drop_keep(unsigned key, unsigned minor, unsigned thresh) {
-    return fmix32(minor ^ key) >= thresh;
+    const unsigned h = fmix32((minor >> 1) ^ key);
+    return ((minor & 1u) ? (h >> 16) : (h & 0xffffu)) >= thresh;
 }
 struct DropArgs {
-    unsigned thresh;  // 0 = dropout off
+    unsigned thresh;  // round(p * 65536); 0 = dropout off
     unsigned seed;
     unsigned stream;
     float scale;      // 1 / (1 - p)

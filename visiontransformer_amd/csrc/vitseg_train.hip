@@ -131,7 +131,8 @@ struct Ctx {
     DropArgs dr(int layer, int site) const {
         DropArgs d{};
         if (drop_p > 0.f) {
-            d.thresh = (unsigned)((double)drop_p * 4294967296.0);
+            d.thresh = (unsigned)((double)drop_p * 65536.0 + 0.5);
+            if (d.thresh == 0) d.thresh = 1;  // p below 2^-17 still drops something rather than switching dropout off
             d.seed = drop_seed;
             d.stream = (unsigned)(layer * 8 + site);
             d.scale = 1.0f / (1.0f - drop_p);
