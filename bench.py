@@ -354,6 +354,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 16 for l16_1024_tiled)")
     ap.add_argument("--precision", default=None, choices=["f32", "bf16", "f16", "f32x3"])
+    ap.add_argument("--classes", type=int, default=2, help="segmentation classes (BASELINE configs use 2; the reference's "
+                                                           "dataset has 17: the decoder tail then writes 17.8 MB/image)")
     ap.add_argument("--workload", default="b16_512", choices=["b16_512", "l16_1024_tiled"],
                     help="b16_512 = BASELINE configs[1] (default, the headline metric); l16_1024_tiled = configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -390,7 +392,7 @@ def main():
     if args.mode in ("prep", "eval"):
         return bench_aux(args, rank, world, dev, barrier)
 
-    cfg = vit_base16(num_classes=2, image_size=512)
+    cfg = vit_base16(num_classes=args.classes, image_size=512)
     B = args.batch
     model = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
                                  cfg.num_attention_heads, image_size=cfg.image_size,
@@ -442,7 +444,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"ViT-B/16 seg inference (forward -> fp32 logits + uint8 sigmoid/argmax mask), "
                                    f"batch {B}/GPU x 512x512, {args.precision} (BASELINE.json configs[1])",
-                       "batch_per_gpu": B, "global_batch": B * world, "image_size": 512, "num_classes": 2,
+                       "batch_per_gpu": B, "global_batch": B * world, "image_size": 512, "num_classes": args.classes,
                        "parallelism": f"batch-split x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
