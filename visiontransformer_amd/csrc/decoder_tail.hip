@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __fmaf_rn(top[e], wy0[r], __fmul_rn(bot[e], wy1[r]));
-            if (logits) *(f32x4*)(logits + (((size_t)b * C + c) * S + Y0 + r) * S + 4 * xq) = v;
+            if (logits)   // streamed once, never re-read by this kernel: keep it out of the caches
+                __builtin_nontemporal_store(v, (f32x4*)(logits + (((size_t)b * C + c) * S + Y0 + r) * S + 4 * xq));
             if (mask) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
