@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                                                                    bf16_t* __restrict__ dqkv, int B, int Np, int A,
                                                                    DropArgs dr) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][TT * HD];  // [buffer][Q|dO]
-    __shared__ float stats[2][2][TT];
+    __shared__ float stats[2][3][TT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const AttnTile at = attn_tile((Np + 1 + TB - 1) / TB, A);
@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
     const int lc = tid & 7, lr = tid >> 3;
     f32x4 rq[2], rd[2];
     float rs = 0.f, rdl = 0.f;
+    unsigned rkey = 0;
     auto gload = [&](int qt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -222,6 +223,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
             const int q = min(qt * TT + tid, N - 1);
             rs = lse[((size_t)b * A + head) * N + q];
             rdl = delta[((size_t)b * A + head) * N + q];
+            // the query's dropout key, hashed ONCE per query here instead of once per (query, key) element below
+            rkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + qt * TT + tid));
         }
     };
     auto swrite = [&](int buf) {
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
         if (tid < TT) {
             stats[buf][0][tid] = rs;
             stats[buf][1][tid] = rdl;
+            stats[buf][2][tid] = __uint_as_float(rkey);
         }
     };
     const int nqt = (N + TT - 1) / TT;
@@ -270,9 +274,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                 if (qt * TT + q1 < N) p1 = __builtin_amdgcn_exp2f(fmaf(st[r + 1], c, -stats[buf][0][q1]));
                 float k0 = 1.f, k1 = 1.f;
                 if (dr.thresh) {
-                    const unsigned base = (unsigned)((b * A + head) * N + qt * TT);
-                    k0 = drop_keep(drop_key(dr.seed, dr.stream, base + q0), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
-                    k1 = drop_keep(drop_key(dr.seed, dr.stream, base + q1), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                    k0 = drop_keep(__float_as_uint(stats[buf][2][q0]), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                    k1 = drop_keep(__float_as_uint(stats[buf][2][q1]), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
                 }
                 pp[r >> 1] = pack2_bf16(p0 * k0, p1 * k1);  // dropped P (what multiplied V in the forward)
                 pd[r >> 1] = pack2_bf16(p0 * (dp[r] * k0 - stats[buf][1][q0]), p1 * (dp[r + 1] * k1 - stats[buf][1][q1]));

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
                                                               const float* __restrict__ delta, float* __restrict__ dqkv,
                                                               int B, int Np, int A, DropArgs dr) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][TT * HD];  // [buffer][Q|dO]
-    __shared__ float stats[2][2][TT];                                  // [buffer][lse|delta]
+    __shared__ float stats[2][3][TT];                                  // [buffer][lse|delta]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const AttnTile at = attn_tile((Np + 1 + TB - 1) / TB, A);
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
     const int lc = tid & 15, lr = tid >> 4;
     f32x4 rq[4], rd[4];
     float rs = 0.f, rdl = 0.f;
+    unsigned rkey = 0;
     auto gload = [&](int qt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -221,6 +222,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
             const int q = min(qt * TT + tid, N - 1);
             rs = lse[((size_t)b * A + head) * N + q];
             rdl = delta[((size_t)b * A + head) * N + q];
+            // the query's dropout key, hashed ONCE per query here instead of once per (query, key) element below
+            rkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + qt * TT + tid));
         }
     };
     auto swrite = [&](int buf) {
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
         if (tid < TT) {
             stats[buf][0][tid] = rs;
             stats[buf][1][tid] = rdl;
+            stats[buf][2][tid] = __uint_as_float(rkey);
         }
     };
 
@@ -273,8 +277,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
                 const float pv = qvalid ? __builtin_amdgcn_exp2f(st[r] - stats[buf][0][qq]) : 0.f;
                 float keep = 1.f;
                 if (dr.thresh)
-                    keep = drop_keep(drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + qt * TT + qq)),
-                                     (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                    keep = drop_keep(__float_as_uint(stats[buf][2][qq]), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
                 st[r] = pv * keep;                                   // dropped P (what multiplied V in the forward)
                 dp[r] = pv * (dp[r] * keep - stats[buf][1][qq]);     // dS
             }
