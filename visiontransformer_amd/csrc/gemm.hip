@@ -1021,22 +1021,39 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_large_kernel(const GemmA
                 const int grow = min(m0 + wm * WROWS + half * 64 + row, p.M - 1);
                 extra[ps] = *(const f32x4*)(p.R + (size_t)grow * p.ldc + min(gcol, p.N - 4));
             }
+            if (EPI == EPI_DGELU) {  // training: R = the saved 16-bit pre-activation
+                const int grow = min(m0 + wm * WROWS + half * 64 + row, p.M - 1);
+                const uint2 u = *(const uint2*)((const T*)p.R + (size_t)grow * p.ldc + min(gcol, p.N - 4));
+                extra[ps][0] = H16<T>::lo(u.x);
+                extra[ps][1] = H16<T>::hi(u.x);
+                extra[ps][2] = H16<T>::lo(u.y);
+                extra[ps][3] = H16<T>::hi(u.y);
+            }
         }
         if (gcol < p.N) {
 #pragma unroll
             for (int ps = 0; ps < 16; ++ps) {
                 const int grow = m0 + wm * WROWS + half * 64 + ps * 4 + rr;
                 const size_t o = (size_t)grow * p.ldc + gcol;
+                f32x4 pre = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = v[ps][e] + bias4[e];
+                    pre[e] = x;
                     if (EPI == EPI_GELU) x = gelu_erf_fast(x);
                     if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
                     if (EPI == EPI_RESADD && p.drop.thresh)
                         x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow), gcol + e, p.drop.thresh)
                                 ? x * p.drop.scale : 0.f;
                     if (EPI == EPI_RESADD) x = extra[ps][e] + x;
+                    if (EPI == EPI_DGELU) x *= gelu_erf_grad(extra[ps][e]);
                     v[ps][e] = x;
+                }
+                if (EPI == EPI_GELU && p.aux && grow < p.M) {  // training: keep the pre-activation for the backward
+                    uint2 h;
+                    h.x = H16<T>::pack2(pre[0], pre[1]);
+                    h.y = H16<T>::pack2(pre[2], pre[3]);
+                    *(uint2*)((T*)p.aux + o) = h;
                 }
                 if (grow < p.M) {
                     if constexpr (sizeof(OutT) == 4) {
@@ -1167,6 +1184,9 @@ int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
                                   : xl ? launch_large<T, T, A_PLAIN, EPI_GELU, 256>(a, s)
                                   : large ? launch_large<T, T, A_PLAIN, EPI_GELU>(a, s)
                                           : launch_one<T, T, A_PLAIN, EPI_GELU>(a, s);
+            case EPI_DGELU: return xl ? launch_large<T, T, A_PLAIN, EPI_DGELU, 256>(a, s)
+                                   : large ? launch_large<T, T, A_PLAIN, EPI_DGELU>(a, s)
+                                           : launch_one<T, T, A_PLAIN, EPI_DGELU>(a, s);
             case EPI_RESADD: return w4 ? launch_large<T, float, A_PLAIN, EPI_RESADD, 256, 4>(a, s)
                                     : xl ? launch_large<T, float, A_PLAIN, EPI_RESADD, 256>(a, s)
                                     : large ? launch_large<T, float, A_PLAIN, EPI_RESADD>(a, s)
@@ -1333,10 +1353,8 @@ int launch_wgrad_bf16_tt(GemmArgs a, float* scratch, hipStream_t s) {
 int launch_gemm_bf16_train(GemmArgs a, int epi, int out_f32, float* scratch, hipStream_t s) {
     VITSEG_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 64 == 0, VITSEG_ESHAPE, "gemm_bf16_train: K=%d %% 64", a.K);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0 && a.lda % 8 == 0, VITSEG_ESHAPE, "gemm_bf16_train: alignment");
-    if (!out_f32) {
-        if (epi == EPI_BIAS) return launch_one<bf16_t, bf16_t, A_PLAIN, EPI_BIAS>(a, s);
-        if (epi == EPI_GELU) return launch_one<bf16_t, bf16_t, A_PLAIN, EPI_GELU>(a, s);
-        if (epi == EPI_DGELU) return launch_one<bf16_t, bf16_t, A_PLAIN, EPI_DGELU>(a, s);
+    if (!out_f32) {  // same tile selection as inference (256x256 for wide outputs, 256x128 for long K, else 128x128)
+        if (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_DGELU) return launch_gemm_h16<bf16_t>(a, A_PLAIN, epi, s);
     } else if (epi == EPI_BIAS) {
         const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
         int splits = (1024 + tiles - 1) / tiles;
