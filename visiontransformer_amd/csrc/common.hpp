@@ -109,6 +109,24 @@ __device__ __forceinline__ float gelu_erf_grad(float u) {
     return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
 }
 
+// the same derivative for 16-bit outputs (bf16 training): A&S 7.1.28 erf (|err| <= 3e-7) and exp2-based phi
+__device__ __forceinline__ float gelu_erf_grad_fast(float u) {
+    const float x = fabsf(u) * 0.70710678118654752440f;
+    float t = fmaf(x, 0.0000430638f, 0.0002765672f);
+    t = fmaf(x, t, 0.0001520143f);
+    t = fmaf(x, t, 0.0092705272f);
+    t = fmaf(x, t, 0.0422820123f);
+    t = fmaf(x, t, 0.0705230784f);
+    t = fmaf(x, t, 1.0f);
+    t = t * t;
+    t = t * t;
+    t = t * t;
+    t = t * t;
+    const float erf_abs = 1.0f - __builtin_amdgcn_rcpf(t);
+    const float cdf = 0.5f + copysignf(0.5f * erf_abs, u);
+    return cdf + u * 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);  // exp(-u^2/2)
+}
+
 // GELU for tensors that are rounded to bf16 right away (relative precision 2^-9): erf by
 // Abramowitz-Stegun 7.1.28, erf x = 1 - (1 + a1 x + ... + a6 x^6)^-16, |abs error| <= 3e-7 -- three
 // orders below the bf16 rounding of the result -- at ~16 plain VALU ops instead of libm's erff.

@@ -506,7 +506,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                         x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow), gcol + e, p.drop.thresh)
                                 ? x * p.drop.scale : 0.f;
                     if (EPI == EPI_RESADD || EPI == EPI_POS) x = extra[ps][e] + x;
-                    if (EPI == EPI_DGELU) x *= gelu_erf_grad(extra[ps][e]);
+                    if (EPI == EPI_DGELU) x *= sizeof(T) == 4 ? gelu_erf_grad(extra[ps][e]) : gelu_erf_grad_fast(extra[ps][e]);
                     v[ps][e] = x;
                 }
                 if (EPI == EPI_GELU && p.aux) {  // pre-activation, saved for the backward pass
@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_large_kernel(const GemmA
                         x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow), gcol + e, p.drop.thresh)
                                 ? x * p.drop.scale : 0.f;
                     if (EPI == EPI_RESADD) x = extra[ps][e] + x;
-                    if (EPI == EPI_DGELU) x *= gelu_erf_grad(extra[ps][e]);
+                    if (EPI == EPI_DGELU) x *= gelu_erf_grad_fast(extra[ps][e]);
                     v[ps][e] = x;
                 }
                 if (EPI == EPI_GELU && p.aux && grow < p.M) {  // training: keep the pre-activation for the backward
