@@ -436,6 +436,33 @@ int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* 
     return VITSEG_OK;
 }
 
+// bf16 -> bf16 copy of the same gather (raw 16-bit moves, 8 channels per thread): the T-form operand of the bf16
+// weight-gradient GEMM of seg_head.0
+__global__ __launch_bounds__(256) void im2col3x3_bf16_kernel(const bf16_t* __restrict__ H, bf16_t* __restrict__ T, int B,
+                                                             int g, int D) {
+    const int nv = D >> 3;
+    const size_t total = (size_t)B * g * g * 9 * nv;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int dv = (int)(i % nv);
+        const int tap = (int)((i / nv) % 9);
+        const size_t m = i / ((size_t)nv * 9);
+        const int x = (int)(m % g), y = (int)((m / g) % g);
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if ((unsigned)yy < (unsigned)g && (unsigned)xx < (unsigned)g)
+            v = *(const uint4*)(H + (m + (ptrdiff_t)(yy - y) * g + (xx - x)) * D + 8 * dv);
+        ((uint4*)T)[i] = v;
+    }
+}
+
+int launch_im2col3x3_bf16(const void* H, void* T, int B, int g, int D, hipStream_t s) {
+    VITSEG_CHECK_ARG(D % 8 == 0, VITSEG_ESHAPE, "im2col3x3_bf16: D %% 8");
+    hipLaunchKernelGGL(im2col3x3_bf16_kernel, dim3(grid_for((size_t)B * g * g * 9 * (D / 8))), dim3(256), 0, s,
+                       (const bf16_t*)H, (bf16_t*)T, B, g, D);
+    VITSEG_LAUNCH_CHECK("im2col3x3_bf16");
+    return VITSEG_OK;
+}
+
 int launch_im2col3x3(const void* H, int h_is_bf16, float* T, int B, int g, int D, hipStream_t s) {
     const dim3 grid(grid_for((size_t)B * g * g * 9 * (D / 4)));
     if (h_is_bf16)

@@ -282,11 +282,15 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
                                  scratch, B, s.Np, s.C, st)))
         return rc;
     if ((rc = launch_colsum(dF, 0, G(VITSEG_T_HEAD0_B), scratch, Mp, MID, MID, st))) return rc;
-    if ((rc = launch_im2col3x3(c.TV(c.p.hf), 1, c.T(c.p.t), B, s.g, D, st))) return rc;
+    // seg_head.0 weight gradient on the bf16 pipe: dF cast to bf16 (into the not-yet-used dXc buffer), the 3x3 im2col of
+    // the bf16 head input gathered as bf16 (half the bytes of the fp32 one), T-form x T-form GEMM over the patch rows
+    if ((rc = launch_cast_bf16(dF, dXc, (size_t)Mp * MID, st))) return rc;
+    if ((rc = launch_im2col3x3_bf16(c.TV(c.p.hf), c.TV(c.p.t), B, s.g, D, st))) return rc;
     {
-        GemmArgs g = lin(dF, c.T(c.p.t), nullptr, nullptr, G(VITSEG_T_HEAD0_W), MID, 9 * D, Mp, MID, 9 * D);
+        GemmArgs g = lin(dXc, c.TV(c.p.t), nullptr, nullptr, G(VITSEG_T_HEAD0_W), MID, 9 * D, Mp, MID, 9 * D);
         g.ldw = 9 * D;
-        if ((rc = launch_wgrad_f32(g, c.T(c.p.wscratch), st))) return rc;
+        g.zeros = c.ws + c.p.zero;
+        if ((rc = launch_wgrad_bf16_tt(g, wscr, st))) return rc;
     }
     if ((rc = launch_conv_dgrad_weight(c.W(VITSEG_T_HEAD0_W), c.T(c.p.wd), D, st))) return rc;
     {
