@@ -1195,6 +1195,9 @@ int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
     } else if (amode == A_CONV3 && epi == EPI_RELU) {
         VITSEG_CHECK_ARG(a.D % 64 == 0 && a.zeros, VITSEG_ESHAPE, "hidden size must be a multiple of 64");
         return large ? launch_large<T, float, A_CONV3, EPI_RELU>(a, s) : launch_one<T, float, A_CONV3, EPI_RELU>(a, s);
+    } else if (amode == A_CONV3 && epi == EPI_BIAS) {  // training: dgrad of the 3x3 conv (correlation with the flipped taps)
+        VITSEG_CHECK_ARG(a.D % 64 == 0 && a.zeros, VITSEG_ESHAPE, "channel count must be a multiple of 64");
+        return large ? launch_large<T, float, A_CONV3, EPI_BIAS>(a, s) : launch_one<T, float, A_CONV3, EPI_BIAS>(a, s);
     }
     set_error("gemm_bf16: unsupported amode/epilogue %d/%d", amode, epi);
     return VITSEG_EINVAL;

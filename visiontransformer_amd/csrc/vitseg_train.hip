@@ -90,7 +90,8 @@ TrainPlan make_train_plan(const Shape& s, int B, int precision) {
     p.dxm = take(MtD);
     if (lp) {
         p.Kpad = up(p.Mt, 64);
-        const size_t wide = (size_t)(s.I > 3 * s.D ? s.I : 3 * s.D);
+        size_t wide = (size_t)(s.I > 3 * s.D ? s.I : 3 * s.D);
+        if (wide < 9 * (size_t)MID) wide = 9 * MID;   // also holds the bf16 copy of the rearranged seg_head.0 weight
         p.dxc = take(p.Mt * s.D * 2);
         p.dhf = take(p.Mp * s.D * 4);
         p.wt = take(wide * s.D * 2);
@@ -293,10 +294,13 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
         if ((rc = launch_wgrad_bf16_tt(g, wscr, st))) return rc;
     }
     if ((rc = launch_conv_dgrad_weight(c.W(VITSEG_T_HEAD0_W), c.T(c.p.wd), D, st))) return rc;
-    {
-        GemmArgs g = lin(dF, c.T(c.p.wd), nullptr, nullptr, dHf, Mp, D, 9 * MID, 0, D);
+    {   // dgrad of the 3x3 conv on the bf16 pipe: the implicit-GEMM gather over the bf16 copy of dF (still in dXc)
+        // against a bf16 copy of the rearranged weight (in the weight-transpose buffer, free until the layer loop)
+        if ((rc = launch_cast_bf16(c.T(c.p.wd), wT, (size_t)D * 9 * MID, st))) return rc;
+        GemmArgs g = lin(dXc, wT, nullptr, nullptr, dHf, Mp, D, 9 * MID, 0, D);
         g.g = s.g; g.Np = s.Np; g.D = MID;
-        if ((rc = launch_gemm_f32_bwd(g, A_CONV3, 0, 0, EPI_BIAS, st))) return rc;
+        g.zeros = c.ws + c.p.zero;
+        if ((rc = launch_gemm_bf16(g, A_CONV3, EPI_BIAS, st))) return rc;
     }
     // ---- 3. final LayerNorm backward ----
     float* dXa = c.T(c.p.dxa);
