@@ -472,6 +472,29 @@ int launch_im2col3x3(const void* H, int h_is_bf16, float* T, int B, int g, int D
     VITSEG_LAUNCH_CHECK("im2col3x3");
     return VITSEG_OK;
 }
+// the same rows rounded to bf16 (T-form operand of the bf16 patch-embedding weight gradient)
+__global__ __launch_bounds__(256) void im2col_patch_bf16_kernel(const float* __restrict__ img, bf16_t* __restrict__ T, int B,
+                                                                int Cin, int S, int P) {
+    const int g = S / P, Kp = Cin * P * P, nv = Kp >> 2;
+    const size_t total = (size_t)B * g * g * nv;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int kv = (int)(i % nv);
+        const size_t m = i / nv;
+        const int gx = (int)(m % g), gy = (int)((m / g) % g), b = (int)(m / ((size_t)g * g));
+        const int k = kv * 4, c = k / (P * P), rem = k - c * P * P, py = rem / P, px = rem - py * P;
+        const f32x4 v = *(const f32x4*)(img + (((size_t)b * Cin + c) * S + gy * P + py) * S + gx * P + px);
+        uint2 h;
+        h.x = pack2_bf16(v[0], v[1]);
+        h.y = pack2_bf16(v[2], v[3]);
+        ((uint2*)T)[i] = h;
+    }
+}
+int launch_im2col_patch_bf16(const float* img, void* T, int B, int Cin, int S, int P, hipStream_t s) {
+    hipLaunchKernelGGL(im2col_patch_bf16_kernel, dim3(grid_for((size_t)B * (S / P) * (S / P) * (Cin * P * P / 4))), dim3(256),
+                       0, s, img, (bf16_t*)T, B, Cin, S, P);
+    VITSEG_LAUNCH_CHECK("im2col_patch_bf16");
+    return VITSEG_OK;
+}
 int launch_im2col_patch(const float* img, float* T, int B, int Cin, int S, int P, hipStream_t s) {
     hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for((size_t)B * (S / P) * (S / P) * (Cin * P * P / 4))), dim3(256),
                        0, s, img, T, B, Cin, S, P);

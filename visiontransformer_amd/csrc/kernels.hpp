@@ -121,6 +121,7 @@ int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* 
                        float* scratch, int B, int Np, int C, hipStream_t s);
 int launch_im2col3x3(const void* H, int h_is_bf16, float* T, int B, int g, int D, hipStream_t s);
 int launch_im2col3x3_bf16(const void* H, void* T, int B, int g, int D, hipStream_t s);
+int launch_im2col_patch_bf16(const float* img, void* T, int B, int Cin, int S, int P, hipStream_t s);
 int launch_im2col_patch(const float* img, float* T, int B, int Cin, int S, int P, hipStream_t s);
 int launch_conv_dgrad_weight(const float* W0, float* Wd, int D, hipStream_t s);
 int launch_embed_bwd(const float* dX, float* dpos, float* dcls, int B, int Np, int D, hipStream_t s);

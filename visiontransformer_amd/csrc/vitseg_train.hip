@@ -355,6 +355,15 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
     if (c.drop_p > 0.f && (rc = launch_dropout_rows(dXa, dXa, 0, Mt, D, c.dr(0, 0), st))) return rc;
     if ((rc = launch_embed_bwd(dXa, G(VITSEG_T_POS), G(VITSEG_T_CLS), B, s.Np, D, st))) return rc;
     if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_PATCH_B), scratch, Mp, D, D, st))) return rc;
+    if (s.Kp % 8 == 0) {  // patch-embedding weight gradient on the bf16 pipe (bf16 patch rows x bf16 dX, fp32 accumulate)
+        if ((rc = launch_cast_bf16(dXa, dXc, (size_t)Mp * D, st))) return rc;
+        if ((rc = launch_im2col_patch_bf16(x, c.TV(c.p.t), B, s.Cin, s.S, s.P, st))) return rc;
+        GemmArgs g = lin(dXc, c.TV(c.p.t), nullptr, nullptr, G(VITSEG_T_PATCH_W), D, s.Kp, Mp, D, s.Kp);
+        g.ldw = s.Kp;
+        g.zeros = c.ws + c.p.zero;
+        if ((rc = launch_wgrad_bf16_tt(g, wscr, st))) return rc;
+        return c.mark(s.L + 1);  // last bucket: embeddings
+    }
     if ((rc = launch_im2col_patch(x, c.T(c.p.t), B, s.Cin, s.S, s.P, st))) return rc;
     GemmArgs g = lin(dXa, c.T(c.p.t), nullptr, nullptr, G(VITSEG_T_PATCH_W), D, s.Kp, Mp, D, s.Kp);
     g.ldw = s.Kp;
