@@ -1108,7 +1108,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 int wgrad_splits(int M, int N, int K) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    int splits = (1024 + tiles - 1) / tiles;         // aim at ~2 rounds of 512 resident blocks
+    int splits = 1024 / tiles;                       // at most 2 whole rounds of the 512 resident blocks (rounding
+                                                     // UP gave 2.04-2.25 rounds: a third, nearly empty one)
     const int ksteps = (K + 31) / 32;
     if (splits > ksteps / 4) splits = ksteps / 4;    // keep >= 4 K steps per slab
     return splits < 1 ? 1 : splits;
@@ -1327,7 +1328,7 @@ int launch_wgrad_bf16_tt(GemmArgs a, float* scratch, hipStream_t s) {
     VITSEG_CHECK_ARG(a.M % 8 == 0 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc == a.N && a.zeros,
                      VITSEG_ESHAPE, "wgrad_bf16_tt: M, N and the leading dimensions must be multiples of 8");
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    int splits = (1024 + tiles - 1) / tiles;
+    int splits = 1024 / tiles;  // <= 2 whole rounds of 512 resident blocks
     const int ksteps = (a.K + 63) / 64;
     if (splits > ksteps / 4) splits = ksteps / 4;
     if (splits < 1) splits = 1;
@@ -1360,7 +1361,7 @@ int launch_gemm_bf16_train(GemmArgs a, int epi, int out_f32, float* scratch, hip
         if (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_DGELU) return launch_gemm_h16<bf16_t>(a, A_PLAIN, epi, s);
     } else if (epi == EPI_BIAS) {
         const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-        int splits = (1024 + tiles - 1) / tiles;
+        int splits = 1024 / tiles;  // <= 2 whole rounds of 512 resident blocks
         if (splits > a.K / 64 / 4) splits = a.K / 64 / 4;
         if (splits <= 1 || !scratch) return launch_one<bf16_t, float, A_PLAIN, EPI_BIAS>(a, s);
         VITSEG_CHECK_ARG(a.ldc == a.N, VITSEG_EINVAL, "gemm_bf16_train: split-K needs a dense output");
@@ -1380,7 +1381,7 @@ int launch_gemm_bf16_train(GemmArgs a, int epi, int out_f32, float* scratch, hip
 }
 size_t wgrad_bf16_scratch_floats(int M, int N, int K) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    int splits = (1024 + tiles - 1) / tiles;
+    int splits = 1024 / tiles;  // <= 2 whole rounds of 512 resident blocks
     if (splits > K / 64 / 4) splits = K / 64 / 4;
     return (size_t)(splits < 1 ? 1 : splits) * M * N;
 }
