@@ -21,6 +21,7 @@ struct TrainPlan {
     LayerBufs lb;                 // offsets inside a layer block
     size_t xfinal, hf, f, z;      // after the last layer
     size_t dxa, dxb, dh, dqkv, du, dctx, dvec, g, dz, df, t, wd, scratch, wscratch, ce_partial, total;
+    size_t wscratch_floats;
     // bf16 training only: bf16 copy of the fp32 residual gradient, transposed weight for dgrad, zero page,
     // fp32 gradient of the final LayerNorm output
     size_t dxc, wt, zero, dhf, Kpad;
@@ -85,6 +86,7 @@ TrainPlan make_train_plan(const Shape& s, int B, int precision) {
         mx(wgrad_scratch_floats(MID, 9 * s.D, Mp));
         mx(wgrad_scratch_floats(s.D, s.Kp, Mp));
         p.wscratch = take(w * 4);
+        p.wscratch_floats = w;
     }
     p.ce_partial = take(ce_partial_count(B, s.S) * 8);
     p.dxm = take(MtD);
@@ -103,7 +105,9 @@ TrainPlan make_train_plan(const Shape& s, int B, int precision) {
         mx(wgrad_bf16_scratch_floats(3 * s.D, s.D, (int)p.Kpad));
         mx(wgrad_scratch_floats(MID, 9 * s.D, (int)p.Mp));  // the head and patch wgrads stay fp32
         mx(wgrad_scratch_floats(s.D, s.Kp, (int)p.Mp));
+        mx(thin_scratch_floats(s.I > 3 * s.D ? s.I : 3 * s.D));   // also the split-K partials of the CLS rows (dgrad, qkv)
         p.wscratch = take(w * 4);
+        p.wscratch_floats = w;
     }
     p.total = off;
     return p;
@@ -204,6 +208,11 @@ int forward_train_bf16(Ctx& c, const float* x, float* logits) {
         if ((rc = launch_layernorm(Xin, c.W(VITSEG_T_LN1_W, l), c.W(VITSEG_T_LN1_B, l), H1, Mt, D, c.eps, true, st)))
             return rc;
         GemmArgs g = lin(H1, c.WL(VITSEG_T_WQKV, l), c.W(VITSEG_T_BQKV, l), nullptr, QKV, Mt, 3 * D, D, D, 3 * D);
+        if (Mp % 256 == 0 && batch <= THIN_MAX_ROWS) {
+            g.thin_rows = batch;
+            g.thin_scratch = c.T(c.p.wscratch);
+            g.thin_capacity = c.p.wscratch_floats;
+        }
         if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_BIAS, st))) return rc;
         if ((rc = launch_attention_bf16(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, c.dr(l, 1), st))) return rc;
         g = lin(CTX, c.WL(VITSEG_T_WO, l), c.W(VITSEG_T_BO, l), Xin, Xmid, Mt, D, D, D, D);
@@ -264,6 +273,11 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
         if ((r = launch_transpose_bf16(Wlp, wT, Nd, Kd, Kd, Nd, st))) return r;
         GemmArgs g = lin(dY, wT, nullptr, (const float*)R, dX, Mt, Kd, Nd, Nd, Kd);
         g.ldw = Nd;
+        if (Mp % 256 == 0 && B <= THIN_MAX_ROWS) {  // CLS rows as a split-K side launch (whole-tile body, see GemmArgs)
+            g.thin_rows = B;
+            g.thin_scratch = wscr;                   // the weight-gradient partial buffer is idle here
+            g.thin_capacity = c.p.wscratch_floats;
+        }
         return launch_gemm_bf16_train(g, epi, 0, nullptr, st);
     };
 
