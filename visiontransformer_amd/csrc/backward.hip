@@ -50,17 +50,35 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const InT* __restri
         partial[(size_t)blockIdx.y * N + c] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-// out[n] = sum_chunks partial[chunk][n]: block = 64 columns x 4 chunk groups, combined through LDS
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                            int chunks, int N) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-    float s = 0.f;
-    if (col < N)
-        for (int c = grp; c < chunks; c += 4) s += partial[(size_t)c * N + col];
-    red[grp][threadIdx.x & 63] = s;
+// out[n] = sum_chunks partial[chunk][n]: block = 64 columns x 16 chunk groups (1024 threads), combined through LDS in a
+// fixed order.  (With 4 groups a thread walked 256 partials of the 1025-chunk training shapes on 24 CUs: 19-62 us for a
+// few MB; 16 groups and unrolled independent loads bring it to the launch-latency scale.)
+constexpr int FIN_GROUPS = 16;
+__device__ __forceinline__ float finish_column(const float* __restrict__ partial, int chunks, size_t stride, int col, int grp,
+                                               float (*red)[64]) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = grp;
+    for (; c + 3 * FIN_GROUPS < chunks; c += 4 * FIN_GROUPS) {
+        s0 += partial[(size_t)c * stride + col];
+        s1 += partial[(size_t)(c + FIN_GROUPS) * stride + col];
+        s2 += partial[(size_t)(c + 2 * FIN_GROUPS) * stride + col];
+        s3 += partial[(size_t)(c + 3 * FIN_GROUPS) * stride + col];
+    }
+    for (; c < chunks; c += FIN_GROUPS) s0 += partial[(size_t)c * stride + col];
+    red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (grp == 0 && col < N) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float v = 0.f;
+    if (grp == 0)
+#pragma unroll
+        for (int k = 0; k < FIN_GROUPS; ++k) v += red[k][threadIdx.x];
+    return v;
+}
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             int chunks, int N) {
+    __shared__ float red[FIN_GROUPS][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const float v = finish_column(partial, chunks, (size_t)N, min(col, N - 1), grp, red);
+    if (grp == 0 && col < N) out[col] = v;
 }
 
 // ---- LayerNorm backward ------------------------------------------------------------------------
@@ -156,18 +174,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         partial[((size_t)blockIdx.x * 2 + 1) * D + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
     }
 }
-// partial[block][2][D] -> dw[D], db[D]: block = 64 columns of the 2D-wide matrix x 4 block groups
-__global__ __launch_bounds__(256) void layernorm_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                   float* __restrict__ db, int blocks, int D) {
-    __shared__ float red[4][64];
+// partial[block][2][D] -> dw[D], db[D]: block = 64 columns of the 2D-wide matrix x 16 block groups
+__global__ __launch_bounds__(1024) void layernorm_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                    float* __restrict__ db, int blocks, int D) {
+    __shared__ float red[FIN_GROUPS][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;  // col in [0, 2D)
-    float s = 0.f;
-    if (col < 2 * D)
-        for (int k = grp; k < blocks; k += 4) s += partial[(size_t)k * 2 * D + col];
-    red[grp][threadIdx.x & 63] = s;
-    __syncthreads();
+    const float v = finish_column(partial, blocks, (size_t)2 * D, min(col, 2 * D - 1), grp, red);
     if (grp == 0 && col < 2 * D) {
-        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
         if (col < D) dw[col] = v; else db[col - D] = v;
     }
 }
@@ -376,7 +389,7 @@ int launch_colsum(const void* X, int x_is_bf16, float* out, float* scratch, int 
         hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3((N + 255) / 256, chunks), dim3(256), 0, s,
                            (const float*)X, scratch, M, N, ld);
     VITSEG_LAUNCH_CHECK("colsum_partial");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, s, scratch, out, chunks, N);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, scratch, out, chunks, N);
     VITSEG_LAUNCH_CHECK("colsum_finish");
     return VITSEG_OK;
 }
@@ -409,7 +422,7 @@ int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is
     else VITSEG_LNB(4);
 #undef VITSEG_LNB
     VITSEG_LAUNCH_CHECK("layernorm_bwd");
-    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, scratch, dw, db, blocks, D);
+    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, s, scratch, dw, db, blocks, D);
     VITSEG_LAUNCH_CHECK("layernorm_bwd_finish");
     return VITSEG_OK;
 }
@@ -429,7 +442,7 @@ int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* 
     hipLaunchKernelGGL(head1x1_bwd_kernel, dim3(blocks), dim3(256), 0, s, dZ, F, W2, dFpre, scratch, B, Np, C);
     VITSEG_LAUNCH_CHECK("head1x1_bwd");
     // scratch is [blocks][C*256]: column sums over the blocks
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C * MID + 63) / 64), dim3(256), 0, s, scratch, dW2, blocks, C * MID);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C * MID + 63) / 64), dim3(1024), 0, s, scratch, dW2, blocks, C * MID);
     VITSEG_LAUNCH_CHECK("head1x1_bwd_finish");
     hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(C), dim3(256), 0, s, dZ, db2, B, Np, C);
     VITSEG_LAUNCH_CHECK("head_bias_bwd");
