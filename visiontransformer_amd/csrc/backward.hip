@@ -32,11 +32,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const InT* __restri
     const int r0 = blockIdx.y * 256 + wave * 64, r1 = min(r0 + 64, M);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (n + 3 < N) {
-        for (int r = r0; r < r1; ++r) {
+        int r = r0;
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+        for (; r + 3 < r1; r += 4) {   // four rows in flight per lane
+            const f32x4 v0 = ld4(X + (size_t)r * ld + n), v1 = ld4(X + (size_t)(r + 1) * ld + n);
+            const f32x4 v2 = ld4(X + (size_t)(r + 2) * ld + n), v3 = ld4(X + (size_t)(r + 3) * ld + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[e] += v0[e];
+                a1[e] += v1[e];
+                a2[e] += v2[e];
+                a3[e] += v3[e];
+            }
+        }
+        for (; r < r1; ++r) {
             const f32x4 v = ld4(X + (size_t)r * ld + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += v[e];
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = (acc[e] + a1[e]) + (a2[e] + a3[e]);
     } else {
         for (int r = r0; r < r1; ++r)
             for (int e = 0; e < 4; ++e)
