@@ -117,16 +117,33 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) dw[i][e] = db[i][e] = 0.f;
     }
-    for (int it = 0; it < 16; ++it) {
-        const int row = blockIdx.x * 64 + it * 4 + wave;
-        if (row >= rows) break;  // wave-uniform
-        f32x4 xv[NV], gv[NV];
+    // the next row's x / g / dres_in are requested before the current row's four dependent wave reductions, so a wave
+    // always has one row of loads in flight (the rows of a wave are 4 apart)
+    f32x4 nx[NV], ng[NV], nd[NV];
+    auto fetch = [&](int row) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = min(lane + 64 * i, nv - 1);
-            xv[i] = ((const f32x4*)(x + (size_t)row * D))[c];
-            gv[i] = ld4(g + (size_t)row * D + 4 * c);
+            nx[i] = ((const f32x4*)(x + (size_t)row * D))[c];
+            ng[i] = ld4(g + (size_t)row * D + 4 * c);
+            if (dres_in) nd[i] = ((const f32x4*)(dres_in + (size_t)row * D))[c];
         }
+    };
+    {
+        const int row0 = blockIdx.x * 64 + wave;
+        if (row0 < rows) fetch(row0);
+    }
+    for (int it = 0; it < 16; ++it) {
+        const int row = blockIdx.x * 64 + it * 4 + wave;
+        if (row >= rows) break;  // wave-uniform
+        f32x4 xv[NV], gv[NV], dv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            xv[i] = nx[i];
+            gv[i] = ng[i];
+            dv[i] = nd[i];
+        }
+        if (it + 1 < 16 && row + 4 < rows) fetch(row + 4);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             const int c = lane + 64 * i;
             if (c < nv) {
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                if (dres_in) o = ((const f32x4*)(dres_in + (size_t)row * D))[c];
+                if (dres_in) o = dv[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += rstd * (gv[i][e] * wv[i][e] - c1 - xv[i][e] * c2);
                 ((f32x4*)(dres_out + (size_t)row * D))[c] = o;
