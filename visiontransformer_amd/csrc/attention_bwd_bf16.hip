@@ -76,7 +76,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int t0, int dt, in
 }
 
 // ---------------------------------------------------------------------------------- dQ
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                   const bf16_t* __restrict__ dctx,
                                                                   const float* __restrict__ lse,
                                                                   const float* __restrict__ delta,
