@@ -26,17 +26,34 @@ __device__ __forceinline__ size_t tok_row(int b, int n, int B, int Np) {
     return n < Np ? (size_t)b * Np + n : (size_t)B * Np + b;
 }
 
-// delta[b][h][n] = sum_d dO[row][h*64+d] * O[row][h*64+d]; one wave per (row, head)
+// delta[b][h][n] = sum_d dO[row][h*64+d] * O[row][h*64+d].  A thread owns 4 consecutive channels (16-byte loads), the 16
+// lanes of a head combine with four lane swaps; threads walk a row, so a wave reads 1 KiB contiguous.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ ctx, const float* __restrict__ dctx,
                                                          float* __restrict__ delta, int B, int Np, int A) {
-    const int lane = threadIdx.x & 63;
-    const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int N = Np + 1;
-    if (item >= (size_t)B * A * N) return;
-    const int n = (int)(item % N), h = (int)((item / N) % A), b = (int)(item / ((size_t)N * A));
-    const size_t off = tok_row(b, n, B, Np) * (size_t)(A * HD) + h * HD + lane;
-    const float v = wave_sum(ctx[off] * dctx[off]);
-    if (lane == 0) delta[item] = v;
+    const int N = Np + 1, cpr = A * 16;                    // 16-byte chunks per row
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)(B * N) * cpr;
+    float v = 0.f;
+    size_t row = 0;
+    int h = 0;
+    if (i < total) {
+        row = i / cpr;
+        const int c = (int)(i - row * cpr);
+        h = c >> 4;
+        const f32x4 o = *(const f32x4*)(ctx + row * (size_t)(A * HD) + c * 4);
+        const f32x4 d = *(const f32x4*)(dctx + row * (size_t)(A * HD) + c * 4);
+        v = (o[0] * d[0] + o[1] * d[1]) + (o[2] * d[2] + o[3] * d[3]);
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if (i < total && (threadIdx.x & 15) == 0) {
+        const size_t BNp = (size_t)B * Np;
+        const int bimg = row < BNp ? (int)(row / Np) : (int)(row - BNp);
+        const int n = row < BNp ? (int)(row - (size_t)bimg * Np) : Np;
+        delta[((size_t)bimg * A + h) * N + n] = v;
+    }
 }
 
 // Shared tile staging: two [64][64] fp32 tiles (X swizzled for 16-byte row reads: chunk ^ (row & 15))
@@ -322,8 +339,8 @@ int launch_attention_bwd_f32(const float* qkv, const float* ctx, const float* dc
                              float* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && dctx && lse && dvec && dqkv, VITSEG_EINVAL, "attention_bwd: null pointer");
     const int N = Np + 1;
-    const size_t items = (size_t)B * A * N;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, ctx, dctx, dvec, B, Np, A);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((size_t)B * N * A * 16 + 255) / 256)), dim3(256), 0, s, ctx, dctx,
+                       dvec, B, Np, A);
     VITSEG_LAUNCH_CHECK("attn_delta");
     const dim3 grid((unsigned)((N + TB - 1) / TB) * A * B);  // 1-D: attn_tile() places the tiles
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
