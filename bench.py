@@ -371,7 +371,9 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # VITSEG_LOCAL_DEVICE / VITSEG_DIST_BACKEND: rehearsal of the N > 1 control flow on a one-GPU box (all ranks on the same
+    # card over gloo); the driver's multi-GPU runs leave both unset (one rank per GPU, nccl = RCCL)
+    local = int(os.environ.get("VITSEG_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
@@ -381,7 +383,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("VITSEG_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
     def barrier():
         if world > 1:
