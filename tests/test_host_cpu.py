@@ -106,3 +106,23 @@ def test_synth_is_deterministic():
     w = synth.make_state_dict(cfg, seed=1)["backbone.layers.0.mlp.fc1.weight"]
     assert abs(w.std() - 0.02) < 5e-4 and abs(w.mean()) < 1e-4
     assert vit_base16().forward_flops_per_image() / 1e9 == pytest.approx(217.7, abs=0.2)
+
+
+def test_dropout_generator_statistics():
+    """The counter-based dropout masks (tests/dropout_ref.py restates csrc/common.hpp): keep rate 1 - p and no visible
+    correlation between neighbouring keys, neighbouring queries or neighbouring layers."""
+    from dropout_ref import Masks
+    m = Masks(0.1, 0x5EED1234ABCD, B=2, Np=255, A=3)
+    a = (m.attn(0, (2, 3, 256, 256)).numpy() > 0).astype(np.float64)          # keep indicators
+    assert abs(a.mean() - 0.9) < 2e-3
+    def corr(x, y):
+        x, y = x.ravel() - x.mean(), y.ravel() - y.mean()
+        return float((x * y).mean() / (x.std() * y.std()))
+    assert abs(corr(a[..., :-1], a[..., 1:])) < 0.01        # neighbouring keys (the two halves of one hash)
+    assert abs(corr(a[..., :-2], a[..., 2:])) < 0.01        # next pair
+    assert abs(corr(a[:, :, :-1], a[:, :, 1:])) < 0.01      # neighbouring queries
+    b = (m.attn(1, (2, 3, 256, 256)).numpy() > 0).astype(np.float64)
+    assert abs(corr(a, b)) < 0.01                           # next layer
+    r = (m.rows(0, 3, (2, 256, 192)).numpy() > 0).astype(np.float64)
+    assert abs(r.mean() - 0.9) < 3e-3 and abs(corr(r[..., :-1], r[..., 1:])) < 0.01
+    assert abs(r.mean(axis=(0, 1)).std()) < 0.02            # no column that is dropped (or kept) systematically
