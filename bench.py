@@ -347,6 +347,38 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
     barrier()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N child processes (one rank per GPU, rendezvous on 127.0.0.1),
+    started BEFORE this process makes any HIP call (a process that has initialised the GPU must not exec/fork GPU work).
+    The parent only waits; rank 0's JSON line goes to stdout unchanged.  Returns the worst child exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):   # a rank died: do not leave the others in a collective
+                break
+        rc = max(abs(c) for c in (p.poll() for p in procs) if c is not None) if any(p.poll() is not None for p in procs) else 1
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                rc = rc or 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,13 +401,18 @@ def main():
     if args.batch is None:
         args.batch = 16 if tiled else 32
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU yet (no HIP call so far), so it only
+        # starts one fresh child per rank and relays their output; the children take the torch.distributed path below
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # VITSEG_LOCAL_DEVICE / VITSEG_DIST_BACKEND: rehearsal of the N > 1 control flow on a one-GPU box (all ranks on the same
     # card over gloo); the driver's multi-GPU runs leave both unset (one rank per GPU, nccl = RCCL)
     local = int(os.environ.get("VITSEG_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (or unset WORLD_SIZE and let "
+                         f"bench.py launch them itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local)

@@ -225,11 +225,59 @@ def forward(x, sd, cfg, stages=None, drop=None):
 
 
 # ----------------------------------------------------------------------------- a14
+def _exp_sleef_u10(d):
+    """fp32 `Sleef_expf{8,16}_u10` (the `Vectorized<float>::exp()` of ATen's AVX2 / AVX-512 builds), restated
+    operation by operation: q = rint(d / ln 2); s = d - q ln2 (two-constant Cody-Waite, fused); degree-6
+    polynomial in s by fused multiply-adds; 1 + (s + s^2 u); scaled by 2^(q>>1) and 2^(q - (q>>1)).
+    Third-party arithmetic (Sleef 3.x `xexpf`, vendored by torch 2.10): pinned bit-for-bit against
+    torch.sigmoid in tests/test_oracle_golden.py::test_sigmoid_restatement_is_atens."""
+    f = torch.float32
+    q = torch.round(d * torch.tensor(1.4426950408889634, dtype=f))      # rint: ties to even
+    s = _fma(q, torch.tensor(-0.693145751953125, dtype=f), d)
+    s = _fma(q, torch.tensor(-1.428606765330187045e-06, dtype=f), s)
+    u = torch.full_like(d, 0.000198527617612853646278381)
+    for c in (0.00139304355252534151077271, 0.00833336077630519866943359, 0.0416664853692054748535156,
+              0.166666671633720397949219, 0.5):
+        u = _fma(u, s, torch.tensor(c, dtype=f))
+    u = 1.0 + _fma(s * s, u, s)
+    qi = q.to(torch.int32)
+    h = qi >> 1
+
+    def pow2(e):
+        return ((e + 127) << 23).view(torch.float32)
+
+    u = (u * pow2(h)) * pow2(qi - h)
+    u = torch.where(d < -104.0, torch.zeros_like(u), u)
+    return torch.where(d > 100.0, torch.full_like(u, float("inf")), u)
+
+
+def sigmoid_aten(x):
+    """`logits.sigmoid()` as ATen's CPU kernel computes it for fp32 (UnaryOpsKernel.cpp sigmoid_kernel, vector
+    path): a = 0 - x; a = a.exp(); a = 1 + a; a = 1 / a.  Restated so that the mask decision -- which hinges on
+    fp32 sigmoid TIES between classes -- does not depend on the host's torch build or thread partition (the
+    scalar tail of a parallel chunk goes through glibc's expf instead).  fp64 inputs: plain sigmoid."""
+    if x.dtype != torch.float32:
+        return x.sigmoid()
+    return 1.0 / (1.0 + _exp_sleef_u10(0.0 - x))
+
+
 def predict_mask(logits):
     """Inference post-processing of the reference scripts: sigmoid THEN argmax over
     classes, first maximal index wins.  model/CE/testViTModel.py:122-126,
     model/CE/datasetTestViTmodel.py:183-190."""
-    return logits.sigmoid().argmax(dim=1)
+    return sigmoid_aten(logits).argmax(dim=1)
+
+
+def mask_stable(logits, eps):
+    """Pixels whose sigmoid -> first-max decision cannot change when every logit moves by at most `eps`
+    (used by the parity tests to exempt ONLY the pixels a logit error of that size can flip): the winner w must
+    stay strictly above every earlier class and at least level with every later one."""
+    w = predict_mask(logits)
+    lo = sigmoid_aten(logits.gather(1, w[:, None]) - eps)      # the winner, pushed down
+    hi = sigmoid_aten(logits + eps)                            # everybody else, pushed up
+    cls = torch.arange(logits.shape[1]).view(1, -1, 1, 1)
+    ok = torch.where(cls < w[:, None], hi < lo, hi <= lo) | (cls == w[:, None])
+    return ok.all(dim=1)
 
 
 # ----------------------------------------------------------------------------- a13

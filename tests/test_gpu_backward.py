@@ -380,3 +380,76 @@ def test_training_step_patch4_against_oracle_autograd(precision, tol):
             continue
         rel = (gv[k].cpu().double() - r.grad).norm().item() / r.grad.norm().item()
         assert rel < tol, (k, rel)
+
+
+# ---------------------------------------------------------------- BASELINE configs[2] at its own image size
+def _vitb_512_case(B, L=1, seed=71):
+    cfg = ViTSegConfig(2, 16, 768, L, 12, image_size=512)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=seed).items()}
+    x = torch.from_numpy(synth.make_images(cfg, B, seed=9))
+    y = torch.from_numpy(synth.make_targets(cfg, B, seed=9, size=512))
+    return cfg, sd, x, y
+
+
+def _grad_check(cfg, arena_grad, leaf, precision):
+    from visiontransformer_amd.params import arena_views
+    gv = arena_views(cfg, arena_grad)
+    worst = 0.0
+    for k, r in leaf.items():
+        if r.grad is None or "pooler" in k:
+            continue
+        a, b = gv[k].cpu().double().flatten(), r.grad.double().flatten()
+        if b.norm() < 1e-7:
+            assert a.norm() < 1e-4, (k, float(a.norm()))
+            continue
+        rel = float((a - b).norm() / b.norm())
+        worst = max(worst, rel)
+        if precision == "fp32":
+            assert rel < 2e-4, (k, rel)
+            assert float((a - b).abs().max()) <= 5e-4 * float(b.abs().max()) + 1e-9, k
+        else:       # bf16 operands (2^-9 relative) through the layer: direction kept, a few per cent of noise
+            cos = float((a @ b) / (a.norm() * b.norm()))
+            assert cos > 0.98 and rel < 0.2, (k, rel, cos)
+    return worst
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_step_vitb_width_512(precision):
+    """ViT-B width (D 768, 12 heads, I 3072), 512x512, batch 8 (M = 8200 token rows), one layer: the shapes at which
+    the bf16 path takes the 256x256 / 256x128 tiles and the CLS rows of the QKV / dgrad GEMMs go through the split-K
+    side launch (vitseg_train.hip forward_train_bf16 / backward_bf16), against autograd on the oracle
+    (model/CE/classes.py:276-285 restated by O.training_step)."""
+    B = 8
+    cfg, sd, x, y = _vitb_512_case(B)
+    torch.set_num_threads(16)
+    leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = O.ce_loss(O.forward(x.double(), leaf, cfg), y)
+    ref.backward()
+    m = ViTSegmentationModel(2, 16, 768, 1, 12, image_size=512, precision=precision, dropout=0.0, device=DEV).train()
+    m.load_state_dict(sd)
+    loss = m.ce_loss(x.to(DEV), y.to(DEV))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref)) < (2e-6 if precision == "fp32" else 5e-3)
+    worst = _grad_check(cfg, m.arena.grad, leaf, precision)
+    print(f"512x512 ViT-B-width training step, {precision}: worst per-tensor relative L2 gradient error {worst:.3e}")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_step_vitb_width_512_dropout_masks_injected(precision):
+    """The same step at batch 4 (M = 4100: the >= 4096-row tiles) in train mode with the reference's dropout 0.1 at the
+    four HF sites; the build's counter-based masks are regenerated in numpy and injected into the oracle."""
+    from dropout_ref import Masks
+    B = 4
+    cfg, sd, x, y = _vitb_512_case(B, seed=72)
+    torch.set_num_threads(16)
+    m = ViTSegmentationModel(2, 16, 768, 1, 12, image_size=512, precision=precision, dropout=0.1, device=DEV).train()
+    m.load_state_dict(sd)
+    seed64 = (m.dropout_seed * 0x9E3779B97F4A7C15 + 1 * 0x100000001B3 + 0) & (2 ** 64 - 1)  # first training forward
+    loss = m.ce_loss(x.to(DEV), y.to(DEV))
+    loss.backward()
+    masks = Masks(0.1, seed64, B, cfg.num_patches, 12)
+    leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = O.ce_loss(O.forward(x.double(), leaf, cfg, drop=masks), y)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref)) < (2e-6 if precision == "fp32" else 5e-3)
+    _grad_check(cfg, m.arena.grad, leaf, precision)

@@ -36,15 +36,25 @@ def test_forward_matches_golden(name):
     err, _ = g.max_abs_err("logits", logits)
     assert err <= TOL_LOGITS * scale, err
     assert g.checksum_rel_err("logits", logits) < 1e-4
-    low = m.debug_buffer(g.batch, _lib.BUF_LOWRES).view(g.batch, g.cfg.num_classes, g.cfg.grid, g.cfg.grid)
-    assert np.abs(low.cpu().numpy() - g.z["lowres_logits.full"]).max() <= TOL_LOGITS * scale
-    # residual stream after the last layer vs the reference's last_hidden_state is checked through the final LN
-    # masks: identical to the reference wherever its decision is not numerically fragile
-    ref = g.mask()
+    low = m.debug_buffer(g.batch, _lib.BUF_LOWRES).view(g.batch, g.cfg.num_classes, g.cfg.grid, g.cfg.grid).cpu()
+    low_err = float(np.abs(low.numpy() - g.z["lowres_logits.full"]).max())
+    assert low_err <= TOL_LOGITS * scale
+    # masks, gate 1 -- "bit-exact" means EVERY pixel: the mask is the reference post-processing (ATen bilinear,
+    # ATen fp32 sigmoid, first-max argmax; testViTModel.py:122-126) of the kernel's own low-res logits, sigmoid ties
+    # and saturated classes included (tiny16_224_c3_sat exists for exactly those pixels).
+    S = g.cfg.image_size
+    own = O.upsample_bilinear(low, (S, S))
+    assert torch.equal(logits.cpu(), own)
     got = mask.cpu().numpy()
-    bad = (got != ref) & ~g.fragile()
+    assert np.array_equal(got, O.predict_mask(own).numpy())
+    # gate 2 -- against the mask of the real reference class: identical on every pixel, except those that a logit
+    # error of the size measured above (fp32 accumulation order, ~1e-6) can flip at all
+    ref = g.mask()
+    ref_logits = O.upsample_bilinear(torch.from_numpy(g.z["lowres_logits.full"]), (S, S))
+    stable = O.mask_stable(ref_logits, 2.0 * low_err + 1e-7).numpy()
+    bad = (got != ref) & stable
     assert bad.sum() == 0, int(bad.sum())
-    assert (got != ref).mean() < 2e-3 if g.head_gain == 1.0 else True
+    assert (~stable).mean() < 2e-3 and (got != ref).mean() < 2e-3, ((~stable).mean(), (got != ref).mean())
     # forward() (logits only) returns the same logits bit for bit
     with torch.no_grad():
         assert torch.equal(m(x), logits)

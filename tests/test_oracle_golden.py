@@ -52,6 +52,26 @@ def test_decoder_tail_bit_exact_given_lowres(name):
     assert np.array_equal(O.predict_mask(up).numpy(), g.mask())
 
 
+def test_sigmoid_restatement_is_atens():
+    """O.sigmoid_aten (Sleef u10 exp restated + exact add / divide) against torch.sigmoid, bit for bit, on sizes that
+    are whole vectors per thread chunk (the scalar tail of a chunk goes through glibc's expf instead)."""
+    torch.manual_seed(0)
+    for scale in (0.5, 2.0, 8.0, 20.0, 60.0, 200.0):
+        x = (torch.randn(1 << 20) * scale).float()
+        assert torch.equal(O.sigmoid_aten(x).view(torch.int32), torch.sigmoid(x).view(torch.int32)), scale
+    edge = torch.tensor([0.0, -0.0, 88.0, -88.0, 103.9, -103.9, 17.32868, 17.4, 1e-8, -1e-8] * 32, dtype=torch.float32)
+    assert torch.equal(O.sigmoid_aten(edge).view(torch.int32), torch.sigmoid(edge).view(torch.int32))
+
+
+def test_mask_stable_flags_only_flippable_pixels():
+    z = torch.tensor([[[[0.0]], [[1e-3]], [[18.0]], [[19.0]]]])           # classes 2 and 3 saturate to 1.0f: first wins
+    assert int(O.predict_mask(z)) == 2 and bool(O.mask_stable(z, 1e-5))
+    z = torch.tensor([[[[1.0]], [[1.0 + 2e-6]]]])                           # class 1 wins by 4e-7: an error of 1e-5 flips it
+    assert int(O.predict_mask(z)) == 1 and not bool(O.mask_stable(z, 1e-5))
+    z = torch.tensor([[[[10.0]], [[10.0 + 2e-6]]]])                         # an fp32 sigmoid tie that stays a tie: first wins
+    assert int(O.predict_mask(z)) == 0 and bool(O.mask_stable(z, 1e-5))
+
+
 def test_resize_target_matches_aten():
     y = torch.randint(0, 5, (3, 256, 256))
     for S in (224, 512, 100, 256):

@@ -43,6 +43,30 @@ __device__ __forceinline__ void taps(int d, float scale, int n_in, int& i0, int&
     w0 = __fsub_rn(1.f, w1);
 }
 
+// `logits.sigmoid()` exactly as ATen's CPU kernel computes it for fp32 (UnaryOpsKernel.cpp sigmoid_kernel, vector path:
+// a = 0 - x; a = Sleef_expf_u10(a); a = 1 + a; a = 1 / a) -- restated operation by operation (oracle/vitseg_oracle.py
+// sigmoid_aten, pinned bit-for-bit against torch.sigmoid): the mask decision hinges on fp32 sigmoid TIES between
+// classes (first index wins), so a 1-ulp difference in exp would move it.  Explicit *_rn intrinsics and fmaf keep
+// hipcc from contracting or re-associating.
+__device__ __forceinline__ float sigmoid_aten(float x) {
+    const float d = __fsub_rn(0.0f, x);
+    const float q = __builtin_rintf(__fmul_rn(d, 1.4426950408889634f));        // ties to even, as cvtps_epi32
+    float s = __fmaf_rn(q, -0.693145751953125f, d);
+    s = __fmaf_rn(q, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = __fmaf_rn(u, s, 0.00139304355252534151077271f);
+    u = __fmaf_rn(u, s, 0.00833336077630519866943359f);
+    u = __fmaf_rn(u, s, 0.0416664853692054748535156f);
+    u = __fmaf_rn(u, s, 0.166666671633720397949219f);
+    u = __fmaf_rn(u, s, 0.5f);
+    u = __fadd_rn(1.0f, __fmaf_rn(__fmul_rn(s, s), u, s));
+    const int qi = (int)q, h = qi >> 1;
+    u = __fmul_rn(__fmul_rn(u, __int_as_float((h + 127) << 23)), __int_as_float((qi - h + 127) << 23));
+    u = d < -104.0f ? 0.0f : u;
+    u = d > 100.0f ? INFINITY : u;
+    return __fdiv_rn(1.0f, __fadd_rn(1.0f, u));
+}
+
 // Thread = a 4 (x) by UPR (y) block of output pixels: the x taps are computed once, and the two horizontally
 // interpolated source rows (`top`, `bot`) are reused while consecutive output rows keep the same source rows (at
 // 16x up-scaling 15 of 16 do; the test is wave-uniform because a wave covers one output row band).
@@ -69,8 +93,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     // an EARLIER class rounds to the same fp32 sigmoid.  That cannot happen when the top-1 logit t1 leads every
     // other class by a margin whose image under sigma is many ulps: |t1| <= 2 (sigma' >= 0.105) and margin >= 1e-4
     // -> the true sigmoids differ by >= 1e-5 ~ 170 ulp(1); |t1| <= 8 (sigma' >= 3.3e-4) and margin >= 4e-3 ->
-    // >= 1.3e-6 ~ 22 ulp -- far beyond the <= 2 ulp error of 1/(1+exp(-x)).  Only the remaining (near-tie or
-    // saturated) pixels evaluate the exact fp32 sigmoids; the result is identical.
+    // >= 1.3e-6 ~ 22 ulp -- far beyond the <= 2 ulp error of ATen's 1/(1+exp(-x)).  Only the remaining (near-tie or
+    // saturated) pixels evaluate the exact fp32 sigmoids (sigmoid_aten above); the result is identical on EVERY pixel.
     float t1[UPR][4], t2[UPR][4];
     int arg[UPR][4];
 #pragma unroll
@@ -124,14 +148,14 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
                 const float at = fabsf(t1[r][e]), margin = t1[r][e] - t2[r][e];
                 amb = amb || !((at <= 2.0f && margin >= 1e-4f) || (at <= 8.0f && margin >= 4e-3f));
             }
-            if (amb) {  // exact path: torch CPU sigmoid 1 / (1 + exp(-x)), first maximal class wins
+            if (amb) {  // exact path: ATen's fp32 sigmoid restated (sigmoid_aten), first maximal class wins
                 float best[4];
                 for (int c = 0; c < C; ++c) {
                     const f32x4 top = hrow(c, y0[r]), bot = hrow(c, y1[r]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v = __fmaf_rn(top[e], wy0[r], __fmul_rn(bot[e], wy1[r]));
-                        const float sg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v)));
+                        const float sg = sigmoid_aten(v);
                         if (c == 0 || sg > best[e]) {
                             best[e] = sg;
                             arg[r][e] = c;

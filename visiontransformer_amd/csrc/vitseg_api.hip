@@ -394,6 +394,32 @@ int vitseg_op_linear_f16(const void* A, const void* Wt, const float* bias, const
     return launch_gemm_bf16(g, A_PLAIN, epilogue, (hipStream_t)stream, true);
 }
 
+int vitseg_op_linear_h16_ex(const void* A, const void* Wt, const float* bias, const void* R, void* C, void* aux, int M,
+                            int N, int K, int epilogue, int f16, int thin_rows, float* scratch, size_t scratch_floats,
+                            float dropout_p, uint32_t dropout_seed, uint32_t dropout_stream, void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "linear_h16_ex: null pointer");
+    VITSEG_CHECK_ARG(epilogue == EPI_BIAS || epilogue == EPI_GELU || epilogue == EPI_RESADD || epilogue == EPI_DGELU,
+                     VITSEG_EINVAL, "linear_h16_ex: epilogue %d", epilogue);
+    VITSEG_CHECK_ARG((epilogue != EPI_RESADD && epilogue != EPI_DGELU) || R, VITSEG_EINVAL, "linear_h16_ex: epilogue needs R");
+    VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "linear_h16_ex: dropout_p %f", dropout_p);
+    GemmArgs g{};
+    g.A = A; g.W = Wt; g.bias = bias; g.R = (const float*)R; g.C = C; g.aux = aux;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
+    if (thin_rows > 0) {
+        g.thin_rows = thin_rows;
+        g.thin_scratch = scratch;
+        g.thin_capacity = scratch_floats;
+    }
+    if (dropout_p > 0.f) {
+        g.drop.thresh = (unsigned)((double)dropout_p * 65536.0 + 0.5);
+        if (g.drop.thresh == 0) g.drop.thresh = 1;
+        g.drop.seed = dropout_seed;
+        g.drop.stream = dropout_stream;
+        g.drop.scale = 1.0f / (1.0f - dropout_p);
+    }
+    return launch_gemm_bf16(g, A_PLAIN, epilogue, (hipStream_t)stream, f16 != 0);
+}
+
 int vitseg_op_gemm_f32(const float* A, const float* Wt, const float* R, float* C, int M, int N, int K, int ta, int tb,
                        int epilogue, void* stream) {
     VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "gemm: null pointer");
