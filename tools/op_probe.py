@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visiontransformer_amd import _lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("op", choices=["linear", "attention", "layernorm"])
+ap.add_argument("op", choices=["linear", "attention", "layernorm", "linear_ex"])
 ap.add_argument("--M", type=int, default=32800)
 ap.add_argument("--N", type=int, default=3072)
 ap.add_argument("--K", type=int, default=768)
@@ -29,7 +29,17 @@ a = ap.parse_args()
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 L = _lib.lib()
-if a.op == "linear" and a.bf16:
+if a.op == "linear_ex":   # 16-bit linear with every epilogue (0 bias, 1 GELU, 2 residual fp32, 5 dGELU), bf16
+    A = torch.randn(a.M, a.K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(a.N, a.K, device=dev) * 0.05).to(torch.bfloat16)
+    b = torch.randn(a.N, device=dev)
+    R = torch.randn(a.M, a.N, device=dev).to(torch.float32 if a.epi == 2 else torch.bfloat16) if a.epi in (2, 5) else None
+    C = R if a.epi == 2 else torch.zeros(a.M, a.N, device=dev, dtype=torch.bfloat16)
+    run = lambda: _lib.check(L.vitseg_op_linear_h16_ex(A.data_ptr(), W.data_ptr(), b.data_ptr() if a.epi != 5 else None,
+                                                       R.data_ptr() if R is not None else None, C.data_ptr(), None, a.M, a.N,
+                                                       a.K, a.epi, 0, 0, None, 0, 0.0, 0, 0, st))
+    work = 2.0 * a.M * a.N * a.K
+elif a.op == "linear" and a.bf16:
     A = torch.randn(a.M, a.K, device=dev).to(torch.bfloat16)
     W = (torch.randn(a.N, a.K, device=dev) * 0.05).to(torch.bfloat16)
     b = torch.randn(a.N, device=dev)

@@ -21,6 +21,8 @@
 // double-buffered in LDS with one barrier per K step; fragments are double-buffered in registers.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace vitseg {
@@ -1170,6 +1172,7 @@ int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
                      a.ldc);
     // the 256x128 / 3-stage kernel and the 128x128 / 2-stage kernel measure within a few % of each other on the
     // model's shapes (both ~790 TF/s asymptote); the large one is used where its deeper prefetch helps: long K
+    if (amode == A_PLAIN && gemm_p8_applies(a, epi)) return launch_gemm_p8(a, epi, s, sizeof(T) == 2 && std::is_same<T, f16_t>::value);
     const char* force = getenv("VITSEG_BF16_TILES");  // "large" / "xl" / "4w" (256x256, 4 waves) / "small" for experiments
     const bool w4 = force && force[0] == '4';
     const bool xl = force ? force[0] == 'x' : (a.M >= 8192 && a.N >= 2048);

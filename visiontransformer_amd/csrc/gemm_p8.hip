@@ -1,0 +1,438 @@
+// 16-bit GEMM for the large linear layers:  C[M,N] = epi(A[M,K] . W[N,K]^T + bias)   (bf16 or IEEE-half operands,
+// fp32 accumulate) -- the QKV / MLP projections of modeling_vit.py:207-254 at the BASELINE batches and the
+// activation-gradient ("dgrad") GEMMs of the training step.
+//
+// Structure (gfx950): persistent 256x256 output tiles, BK = 64, 8 waves as 2 (M) x 4 (N), 128x64 per wave
+// (128 accumulator registers), v_mfma_f32_16x16x32.  One block per CU owns the whole 160 KiB LDS:
+//   * a ring of 8 "half-tiles" (16 KiB = 128 operand rows x 64 k): per K step A0 | B0 | B1 | A1, where A-half h holds
+//     rows {wr * 128 + h * 64 + i} of both wave rows and B-half h columns {wc * 64 + h * 32 + i} of all four wave
+//     columns, so that quadrant (ha, hb) of every wave's sub-tile needs exactly A-half ha and B-half hb;
+//   * filled by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB = 8 rows per wave instruction, XOR swizzle applied to the
+//     per-lane SOURCE chunk), issued SIX half-tiles ahead of their first read and waited for with counted
+//     s_waitcnt vmcnt(6|8): the stream never drains inside the loop and runs on across tile boundaries, so
+//     a tile's prologue is hidden behind its predecessor;
+//   * a K step is 4 phases = the 4 quadrants (a0,b0) (a0,b1) (a1,b1) (a1,b0): each phase reads only the fragments
+//     that change (8 A or 4 B ds_read_b128) and issues 16 MFMAs.  The two wave rows run the same program one
+//     barrier interval apart, so on every SIMD one wave is in its MFMA segment while its partner reads LDS and
+//     issues DMA ("ping-pong"); s_setprio pins the MFMA clusters between the raw s_barriers.
+//   * The accumulators hold C TRANSPOSED (MFMA A operand = W rows, B operand = activation rows): a lane then owns 4
+//     consecutive output columns of one row, which it parks as one 16-byte LDS write in a wave-private 4 KiB
+//     staging slab (outside the ring, so the operand stream keeps flowing); the slab is read back row-wise for
+//     the bias / GELU / residual / dropout arithmetic and whole-line global stores.
+// Roofline: MFMA bf16/f16 dense 2.5 PFLOP/s; algorithmic work 2 M N K per launch.
+#include <stdlib.h>
+
+#include "kernels.hpp"
+
+namespace vitseg {
+namespace {
+
+constexpr int PT = 256;                 // tile edge (M and N)
+constexpr int HALF_BYTES = 16384;       // 128 rows x 128 B
+constexpr int RING_BYTES = 8 * HALF_BYTES;
+constexpr int STAGE_BYTES = 4096;       // per wave: [16 rows][64 cols] fp32
+constexpr int P8_LDS = RING_BYTES + 8 * STAGE_BYTES;   // 163 840 B = the whole LDS of a CU
+
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma16<f16_t> {
+    static __device__ __forceinline__ f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+struct TileCoord {
+    int m0, n0;
+};
+// Logical tile order: column groups of GN tiles, row panels marching inside a group; the 32 blocks of one XCD
+// (blockIdx % 8 equal) take 32 consecutive logical tiles of every round = an (8 x 4)-ish patch that shares operand
+// panels through that XCD's L2.
+__device__ __forceinline__ TileCoord tile_coord(int round, int tiles_m, int tiles_n, int gn) {
+    const int first = round * (int)gridDim.x;
+    const int live = min((int)gridDim.x, tiles_m * tiles_n - first);   // blocks that still have a tile in this round
+    const int t = first + xcd_remap(min((int)blockIdx.x, live - 1), live);
+    const int gsz = tiles_m * gn, ngroups = (tiles_n + gn - 1) / gn;
+    const int grp = min(t / gsz, ngroups - 1);
+    const int rem = t - grp * gsz;
+    const int gcols = min(gn, tiles_n - grp * gn);
+    TileCoord c;
+    const int tm = rem / gcols;
+    c.m0 = tm * PT;
+    c.n0 = (grp * gn + rem - tm * gcols) * PT;
+    return c;
+}
+
+template <typename T, typename OutT, int EPI>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // ring | per-wave staging (ONE array: see the guide)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int tiles_m = (p.M + PT - 1) / PT, tiles_n = p.N / PT;
+    const int ntiles = tiles_m * tiles_n;
+    const int gn = (tiles_n % 4 == 0) ? 4 : (tiles_n % 3 == 0 ? 3 : (tiles_n >= 4 ? 4 : tiles_n));
+    const int KT = p.K / 64;
+    // this block's tiles: blockIdx.x, blockIdx.x + gridDim.x, ...
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_k = my_tiles * KT;            // K steps this block walks
+
+    // ---- DMA side: per-lane byte offsets inside a tile (constant for the whole kernel) ----
+    unsigned voffA[2][2], voffW[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            const int i = 16 * wave + 8 * pc + (lane >> 3);          // row inside the half-tile
+            const int cpos = (lane & 7) ^ ((i >> 1) & 7);            // logical chunk stored at position lane & 7
+            const int ra = (i >> 6) * 128 + h * 64 + (i & 63);
+            const int rw = (i >> 5) * 64 + h * 32 + (i & 31);
+            voffA[h][pc] = (unsigned)ra * (unsigned)p.lda * 2u + cpos * 16;
+            voffW[h][pc] = (unsigned)rw * (unsigned)p.ldw * 2u + cpos * 16;
+        }
+    // issue side: two cursors, because one K step G issues halves B1 / A1 of step G + 1 (cursor 0, phases 0 and 1) and
+    // A0 / B0 of step G + 2 (cursor 1, phases 2 and 3); both advance once per K step.  A cursor is a pair of buffer
+    // descriptors rebased to the tile (rows beyond M are out of range and read as zeros) plus the K byte offset.
+    // The DMA is issued from inline asm on purpose: hipcc then keeps its ordinary exact vmcnt bookkeeping for the
+    // epilogue's loads and stores (with an LDS-DMA builtin in the kernel it waits vmcnt(0) before every use of a ds_read
+    // or global-load result, which serialises the epilogue store by store); the ring is ordered by hand-counted waits.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    struct Cursor {
+        i32x4 a, w;       // raw buffer descriptors {base lo, base hi, num_records, flags}
+        unsigned soff;    // K byte offset inside the tile's rows
+        int ts, kt;       // tile sequence number of this block, K step inside the tile
+    };
+    Cursor cur0, cur1;
+    auto make_rsrc = [](const void* base, size_t bytes) {
+        const unsigned long long b = (unsigned long long)base;
+        i32x4 r;
+        r[0] = (int)(unsigned)b;
+        r[1] = (int)(unsigned)((b >> 32) & 0xffffu);                       // stride 0
+        r[2] = (int)(unsigned)(bytes < 0x7fffffffull ? bytes : 0x7fffffffull);
+        r[3] = 0x00020000;
+        return r;
+    };
+    auto set_tile = [&](Cursor& c) {
+        if (c.ts < my_tiles) {
+            const TileCoord tc = tile_coord(c.ts, tiles_m, tiles_n, gn);
+            c.a = make_rsrc((const T*)p.A + (size_t)tc.m0 * p.lda, (size_t)(p.M - tc.m0) * p.lda * 2);
+            c.w = make_rsrc((const T*)p.W + (size_t)tc.n0 * p.ldw, (size_t)PT * p.ldw * 2);
+        } else {                               // past the end: zero-record descriptors, the DMA moves nothing
+            c.a = make_rsrc(p.A, 0);
+            c.w = make_rsrc(p.W, 0);
+        }
+    };
+    auto set_cursor = [&](Cursor& c, int gstep) {   // gstep: index of the K step in this block's stream
+        c.ts = gstep / KT;
+        c.kt = gstep - c.ts * KT;
+        c.soff = (unsigned)c.kt * 128u;
+        set_tile(c);
+    };
+    auto advance = [&](Cursor& c) {                 // next K step of the stream
+        ++c.kt;
+        c.soff += 128u;
+        if (c.kt == KT) {
+            c.kt = 0;
+            c.soff = 0;
+            ++c.ts;
+            set_tile(c);
+        }
+    };
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    auto issue_half = [&](const Cursor& c, int j, int region) {   // j: 0 A0, 1 B0, 2 B1, 3 A1
+        const bool isA = (j == 0 || j == 3);
+        const int h = (j == 0 || j == 1) ? 0 : 1;
+        const unsigned dst = lds_base + region * HALF_BYTES + (16 * wave) * 128;
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            // M0 = LDS destination of the wave's 1 KiB piece (lane l lands at + 16 l); written in the same statement
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst + pc * 1024), "v"(isA ? voffA[h][pc] : voffW[h][pc]), "s"(isA ? c.a : c.w), "s"(c.soff)
+                         : "memory");
+        }
+    };
+
+    // ---- fragment side ----
+    const int sw = l15 >> 1;
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_rd[ks] = (wr * 64 + l15) * 128 + (((4 * ks + lq) ^ sw) << 4);
+        b_rd[ks] = (wc * 32 + l15) * 128 + (((4 * ks + lq) ^ sw) << 4);
+    }
+    bf16x8 xa[4][2];          // activation fragments of the current A-half: [m tile][k step]
+    bf16x8 wx[2][2], wy[2][2];  // weight fragments of the two B-halves (roles alternate per K step)
+    auto read_a = [&](int region) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                xa[mt][ks] = *(const bf16x8*)(lds + region * HALF_BYTES + mt * 2048 + a_rd[ks]);
+    };
+    auto read_b = [&](bf16x8 (&w)[2][2], int region) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                w[nt][ks] = *(const bf16x8*)(lds + region * HALF_BYTES + nt * 2048 + b_rd[ks]);
+    };
+    f32x4 acc[8][4];          // [m tile][n tile]: rows n = 4 lq + r, column m = l15 (C transposed)
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto mfma_quad = [&](int ha, int hb, bf16x8 (&w)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[ha * 4 + mt][hb * 2 + nt] = Mfma16<T>::run(w[nt][ks], xa[mt][ks], acc[ha * 4 + mt][hb * 2 + nt]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define P8_BAR()                              \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+#define P8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+    // ---- epilogue of one tile (both wave rows run it in the same barrier interval) ----
+    float* stage = (float*)(lds + RING_BYTES + wave * STAGE_BYTES);
+    auto epilogue = [&](const TileCoord tc) {
+        constexpr bool OUT16 = sizeof(OutT) == 2;
+        const int gcol0 = tc.n0 + wc * 64;
+        // row side: OUT16: lane -> rows (lane >> 3) + 8 i, 8 columns 8 (lane & 7); fp32: rows (lane >> 4) + 4 i, 4 columns
+        constexpr int CPL = OUT16 ? 8 : 4;                 // columns per lane
+        constexpr int LPR = 64 / CPL;                      // lanes per row
+        constexpr int RPI = 64 / LPR;                      // rows per instruction
+        const int rrow = lane / LPR, rcol = (lane % LPR) * CPL;
+        float bias_r[CPL];
+#pragma unroll
+        for (int c4 = 0; c4 < CPL / 4; ++c4) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) b4 = *(const f32x4*)(p.bias + gcol0 + rcol + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bias_r[c4 * 4 + e] = b4[e];
+                asm volatile("" : "+v"(bias_r[c4 * 4 + e]));   // consume here: the only wait for this load sits here
+            }
+        }
+        constexpr int NI = 16 / RPI;                       // row groups per 16-row slab
+        constexpr bool HAS_EXTRA = EPI == EPI_RESADD || EPI == EPI_DGELU;
+        // operand of the epilogue arithmetic (residual rows / saved pre-activation), fetched ONE slab ahead: vmcnt retires
+        // in issue order, so a load issued after the previous slab's stores could only be waited for together with them
+        float extra[2][NI][CPL];
+        auto row_of = [&](int mt, int i) { return tc.m0 + wr * 128 + mt * 16 + rrow + RPI * i; };
+        auto off_of = [&](int mt, int i) {
+            const int g = row_of(mt, i);
+            return (size_t)(g < p.M ? g : 0) * p.ldc + gcol0 + rcol;
+        };
+        auto load_extra = [&](int buf, int mt) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (EPI == EPI_RESADD) {
+                    const f32x4 r4 = *(const f32x4*)(p.R + off_of(mt, i));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) extra[buf][i][e] = r4[e];
+                }
+                if (EPI == EPI_DGELU) {   // R = the saved 16-bit pre-activation
+                    const uint4 u = *(const uint4*)((const T*)p.R + off_of(mt, i));
+                    const unsigned uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        extra[buf][i][2 * e] = H16<T>::lo(uu[e]);
+                        extra[buf][i][2 * e + 1] = H16<T>::hi(uu[e]);
+                    }
+                }
+            }
+        };
+        if (HAS_EXTRA) load_extra(0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            // park the 16 x 64 slab: lane writes 4 consecutive columns (n = nt * 16 + 4 lq + r) of row l15
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *(f32x4*)(stage + l15 * 64 + (((nt * 4 + lq) ^ l15) << 2)) = acc[mt][nt];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private: no barrier needed
+            float v[NI][CPL];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = rrow + RPI * i;
+#pragma unroll
+                for (int c4 = 0; c4 < CPL / 4; ++c4) {
+                    const f32x4 t = *(const f32x4*)(stage + row * 64 + ((((rcol >> 2) + c4) ^ row) << 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][c4 * 4 + e] = t[e];
+                }
+            }
+            if (HAS_EXTRA && mt + 1 < 8) load_extra((mt + 1) & 1, mt + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab is free for the next m tile
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int grow = row_of(mt, i);
+                const size_t o = off_of(mt, i);
+                float pre[CPL];
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) {
+                    float x = v[i][e] + bias_r[e];
+                    pre[e] = x;
+                    if (EPI == EPI_GELU) x = gelu_erf_fast(x);
+                    if (EPI == EPI_RESADD && p.drop.thresh)
+                        x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow), gcol0 + rcol + e, p.drop.thresh)
+                                ? x * p.drop.scale : 0.f;
+                    if (EPI == EPI_RESADD) x = extra[mt & 1][i][e] + x;
+                    if (EPI == EPI_DGELU) x *= gelu_erf_grad_fast(extra[mt & 1][i][e]);
+                    v[i][e] = x;
+                }
+                if constexpr (OUT16) {
+                    uint4 h, ha;
+                    h.x = H16<OutT>::pack2(v[i][0], v[i][1]); h.y = H16<OutT>::pack2(v[i][2], v[i][3]);
+                    h.z = H16<OutT>::pack2(v[i][4], v[i][5]); h.w = H16<OutT>::pack2(v[i][6], v[i][7]);
+                    ha.x = H16<T>::pack2(pre[0], pre[1]); ha.y = H16<T>::pack2(pre[2], pre[3]);
+                    ha.z = H16<T>::pack2(pre[4], pre[5]); ha.w = H16<T>::pack2(pre[6], pre[7]);
+                    if (grow < p.M) {
+                        if (EPI == EPI_GELU && p.aux) *(uint4*)((T*)p.aux + o) = ha;
+                        *(uint4*)((OutT*)p.C + o) = h;
+                    }
+                } else {
+                    if (grow < p.M) *(f32x4*)((float*)p.C + o) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+                }
+            }
+        }
+    };
+
+    // ---- prologue: fill the stream (halves 0 .. 5 of the block's sequence), first B0 fragments ----
+    // stream order per K step G: A0 (region 4s), B0 (4s+1), B1 (4s+2), A1 (4s+3), s = G & 1
+    set_cursor(cur0, 0);
+    set_cursor(cur1, 1);
+    issue_half(cur0, 0, 0); issue_half(cur0, 1, 1); issue_half(cur0, 2, 2); issue_half(cur0, 3, 3);   // step 0
+    issue_half(cur1, 0, 4); issue_half(cur1, 1, 5);                                                    // step 1: A0, B0
+    P8_VMCNT(8);                              // step 0's A0, B0 landed (this wave's pieces)
+    P8_BAR();
+    zero_acc();
+    read_b(wx, 1);                            // B0 of step 0
+    // cursor 0 now follows step G+1 (B1, A1), cursor 1 step G+2 (A0, B0)
+    set_cursor(cur0, 1);
+    set_cursor(cur1, 2);
+    if (wr == 1) P8_BAR();                    // wave row 1 runs one barrier interval behind wave row 0
+
+    TileCoord tc_cur = tile_coord(0, tiles_m, tiles_n, gn);
+    int kt_in_tile = 0, tile_seq = 0;
+    // one K step; `s` = parity of the step, (w0, w1) = (fragments holding this step's B0, the other buffer)
+#define P8_KSTEP(s, w0, w1, G)                                                                       \
+    do {                                                                                             \
+        /* phase 0: quadrant (a0, b0) */                                                             \
+        read_a(4 * (s) + 0);                                                                         \
+        issue_half(cur0, 2, 4 * ((s) ^ 1) + 2);                                                         \
+        P8_VMCNT(8);                                                                                 \
+        P8_BAR();                                                                                    \
+        mfma_quad(0, 0, w0);                                                                         \
+        P8_BAR();                                                                                    \
+        /* phase 1: (a0, b1) */                                                                      \
+        read_b(w1, 4 * (s) + 2);                                                                     \
+        issue_half(cur0, 3, 4 * ((s) ^ 1) + 3);                                                         \
+        P8_VMCNT(8);                                                                                 \
+        P8_BAR();                                                                                    \
+        mfma_quad(0, 1, w1);                                                                         \
+        P8_BAR();                                                                                    \
+        /* phase 2: (a1, b1) */                                                                      \
+        read_a(4 * (s) + 3);                                                                         \
+        issue_half(cur1, 0, 4 * (s) + 0);                                                               \
+        P8_VMCNT(6);                                                                                 \
+        P8_BAR();                                                                                    \
+        mfma_quad(1, 1, w1);                                                                         \
+        P8_BAR();                                                                                    \
+        /* phase 3: (a1, b0); the next step's B0 goes into the buffer b1 just vacated */             \
+        read_b(w1, 4 * ((s) ^ 1) + 1);                                                               \
+        issue_half(cur1, 1, 4 * (s) + 1);                                                               \
+        advance(cur0);                                                                               \
+        advance(cur1);                                                                               \
+        P8_VMCNT(8);                                                                                 \
+        P8_BAR();                                                                                    \
+        mfma_quad(1, 0, w0);                                                                         \
+        P8_BAR();                                                                                    \
+    } while (0)
+
+    for (int G = 0; G < total_k; G += 2) {
+        P8_KSTEP(0, wx, wy, G);
+        P8_KSTEP(1, wy, wx, G + 1);
+        kt_in_tile += 2;
+        if (kt_in_tile == KT) {   // tile complete (KT is even): both wave rows run the epilogue in the SAME interval
+            if (wr == 0) P8_BAR();
+            epilogue(tc_cur);
+            if (wr == 1) P8_BAR();
+            zero_acc();
+            kt_in_tile = 0;
+            ++tile_seq;
+            if (tile_seq < my_tiles) tc_cur = tile_coord(tile_seq, tiles_m, tiles_n, gn);
+        }
+    }
+    if (wr == 0) P8_BAR();
+    P8_VMCNT(0);
+#undef P8_KSTEP
+}
+
+}  // namespace
+
+// true when the 8-phase kernel takes this GEMM (plain A, whole 256-column tiles, an even number of 64-deep K steps)
+bool gemm_p8_applies(const GemmArgs& a, int epi) {
+    if (getenv("VITSEG_NO_P8")) return false;   // A/B against the previous kernels (tools/gemm_probe.py)
+    const size_t a_bytes = ((size_t)a.M + PT) * a.lda * 2, w_bytes = (size_t)a.N * (a.ldw ? a.ldw : a.K) * 2;
+    return a.M >= 2048 && a.N % PT == 0 && a.K % 128 == 0 && a.K >= 256 && a.lda % 8 == 0 && a.ldc % 8 == 0 &&
+           (a.ldw == 0 || a.ldw % 8 == 0) && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull && a.splitk <= 1 &&
+           (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESADD || epi == EPI_DGELU);
+}
+
+template <typename T, typename OutT, int EPI>
+static int launch_p8_one(GemmArgs a, hipStream_t s) {
+    if (a.ldw == 0) a.ldw = a.K;
+    const int tiles = ((a.M + PT - 1) / PT) * (a.N / PT);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hip_fail(hipGetLastError(), "device properties");
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_p8_kernel<T, OutT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_p8)");
+        attr_set = true;
+    }
+    const int grid = tiles < ncu ? tiles : ncu;
+    hipLaunchKernelGGL((gemm_p8_kernel<T, OutT, EPI>), dim3(grid), dim3(512), P8_LDS, s, a);
+    VITSEG_LAUNCH_CHECK("gemm_p8");
+    return VITSEG_OK;
+}
+
+template <typename T>
+static int launch_p8_t(const GemmArgs& a, int epi, hipStream_t s) {
+    switch (epi) {
+        case EPI_BIAS: return launch_p8_one<T, T, EPI_BIAS>(a, s);
+        case EPI_GELU: return launch_p8_one<T, T, EPI_GELU>(a, s);
+        case EPI_DGELU: return launch_p8_one<T, T, EPI_DGELU>(a, s);
+        case EPI_RESADD: return launch_p8_one<T, float, EPI_RESADD>(a, s);
+    }
+    set_error("gemm_p8: unsupported epilogue %d", epi);
+    return VITSEG_EINVAL;
+}
+
+int launch_gemm_p8(const GemmArgs& a, int epi, hipStream_t s, bool f16) {
+    return f16 ? launch_p8_t<f16_t>(a, epi, s) : launch_p8_t<bf16_t>(a, epi, s);
+}
+
+}  // namespace vitseg

@@ -69,6 +69,9 @@ int launch_gemm_bf16_train(GemmArgs a, int epi, int out_f32, float* scratch, hip
 size_t wgrad_bf16_scratch_floats(int M, int N, int K);
 // 16-bit operands, fp32 accumulate; f16 selects IEEE half instead of bf16 (inference formats, common.hpp H16<>)
 int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s, bool f16 = false);
+// persistent 8-phase 256x256 kernel for the large plain linear layers (gemm_p8.hip); `applies` = shape / alignment test
+bool gemm_p8_applies(const GemmArgs& a, int epi);
+int launch_gemm_p8(const GemmArgs& a, int epi, hipStream_t s, bool f16);
 
 // LayerNorm over the last dim (a4); out_fmt: 0 fp32 output, 1 bf16, 2 IEEE half.
 int launch_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int D, float eps,
