@@ -154,14 +154,21 @@ int vitseg_op_linear_f16(const void* A, const void* W, const float* bias, const 
                          int epilogue, void* stream);
 int vitseg_op_attention_f16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream);
 /* The 16-bit linear layer with every epilogue / dispatch option the training path uses (exported so the parity
- * tests can reach each shape-selected tile variant): epilogue 0 bias, 1 bias+GELU (aux != NULL: also stores the
- * 16-bit pre-activation), 2 residual R fp32 [M,N] + dropout(acc + bias) with fp32 output, 5 acc * gelu'(R), R = 16-bit
- * pre-activation [M,N].  f16: IEEE half instead of bf16.  thin_rows > 0: the last thin_rows rows (the CLS rows of the
+ * tests can reach each shape-selected tile variant): epilogue 0 bias, 1 bias+GELU (aux != NULL: also stores
+ * gelu'(pre-activation) in the 16-bit format -- what the backward multiplies by), 2 residual R fp32 [M,N] +
+ * dropout(acc + bias) with fp32 output, 5 acc * R with R = that saved 16-bit derivative [M,N].  f16: IEEE half instead of bf16.  thin_rows > 0: the last thin_rows rows (the CLS rows of the
  * patches-first layout) go through the split-K side launch (scratch: fp32 partials).  dropout_p > 0 (epilogue 2):
  * keep(seed, stream, row, col) of csrc/common.hpp, i.e. hidden dropout of modeling_vit.py:276,283. */
 int vitseg_op_linear_h16_ex(const void* A, const void* W, const float* bias, const void* R, void* C, void* aux, int M,
                             int N, int K, int epilogue, int f16, int thin_rows, float* scratch, size_t scratch_floats,
                             float dropout_p, uint32_t dropout_seed, uint32_t dropout_stream, void* stream);
+/* bf16 weight gradient dW[M,N] (fp32) = dY^T X with dY = [K tokens][M], X = [K tokens][N] bf16 row-major (the form
+ * autograd's linear backward meets: both operands lie token-major, the reduction runs over the token rows); split over
+ * the token rows, fp32 partials in `scratch` (>= vitseg_op_wgrad_bf16_scratch_floats floats), fixed-order reduce.
+ * zeros: >= 256 zero bytes on the device. */
+size_t vitseg_op_wgrad_bf16_scratch_floats(int M, int N, int K);
+int vitseg_op_wgrad_bf16(const void* dY, const void* X, float* dW, float* scratch, const void* zeros, int M, int N, int K,
+                         void* stream);
 /* lowres fp32 [B, C, g, g] -> logits fp32 [B, C, S, S] and/or mask uint8 [B, S, S] */
 int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask, int batch, int C, int g, int S,
                               void* stream);

@@ -290,12 +290,12 @@ def test_linear_h16_tile_variants(M, N, K, epi, extra, fmt):
             y = y * _drop_rows_np(M, N, p, seed, stream_id).double()
         ref = R.double() + y
     elif epi == 5:
-        U = _rand(M, N, seed=12).to(dt)                    # the saved 16-bit pre-activation
+        U = _gelu_grad64(_rand(M, N, seed=12).double()).float().to(dt)   # the saved 16-bit gelu'(pre-activation)
         Ud = U.to(DEV)
         Rp = Ud.data_ptr()
         C = torch.zeros(M, N, device=DEV, dtype=dt)
         bd = None
-        ref = acc * _gelu_grad64(U.double())
+        ref = acc * U.double()
     else:
         C = torch.zeros(M, N, device=DEV, dtype=dt)
         Rp = None
@@ -307,8 +307,34 @@ def test_linear_h16_tile_variants(M, N, K, epi, extra, fmt):
     got = C.float().cpu().double()
     if epi == 2:      # fp32 output: fp32 accumulation error only
         assert (got - ref).abs().max().item() < 4e-7 * scale * (1.2 if p else 1.0) + 1e-5
-    else:             # one rounding to the 16-bit format (dGELU: the fast erf/exp2 derivative, |err| <= 1e-6)
-        assert ((got - ref).abs() <= ulp * ref.abs() + 4e-7 * scale + 2e-6 * (acc.abs() if epi == 5 else 1.0)).all()
-    if aux is not None:
-        pre = acc + bias.double()
-        assert ((aux.float().cpu().double() - pre).abs() <= ulp * pre.abs() + 4e-7 * scale + 1e-6).all()
+    else:             # one rounding to the 16-bit format
+        assert ((got - ref).abs() <= ulp * ref.abs() + 4e-7 * scale + 2e-6).all()
+    if aux is not None:   # the forward saves gelu'(pre-activation) for the backward (A&S 7.1.28 erf + exp2: |err| <= 1e-6)
+        dref = _gelu_grad64(acc + bias.double())
+        assert ((aux.float().cpu().double() - dref).abs() <= ulp * dref.abs() + 4e-7 * scale + 2e-6).all()
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (768, 3072, 8200),        # dW of fc2 at 8 images: 36 tiles of 256x256, sliced over the token rows (8-phase TT kernel)
+    (3072, 768, 4100),        # dW of fc1; ragged last 64-token step
+    (768, 768, 2050),         # dW of o_proj / patch embedding
+    (2304, 768, 1025),        # dW of the fused QKV projection, one image
+    (256, 6912, 2048),        # dW of seg_head.0 (im2col columns)
+    (192, 576, 788),          # small (Tiny) shapes: the 128x128 TT kernel
+    (128, 136, 70),
+])
+def test_wgrad_bf16_both_operands_token_major(M, N, K):
+    """dW = dY^T X with both operands as they lie in memory ([tokens][columns]), no transposed copies: the MFMA
+    operands are gathered with transposed LDS reads.  fp64 reference of the same bf16 values."""
+    dY = _rand(K, M, seed=K).to(torch.bfloat16)
+    X = _rand(K, N, seed=N + 3, scale=0.5).to(torch.bfloat16)
+    ref = dY.double().T @ X.double()
+    scale = float((dY.abs().double().T @ X.abs().double()).max())
+    dYd, Xd = dY.to(DEV), X.to(DEV)
+    dW = torch.full((M, N), float("nan"), device=DEV)
+    zeros = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    n = _lib.lib().vitseg_op_wgrad_bf16_scratch_floats(M, N, K)
+    scratch = torch.empty(n, device=DEV)
+    _lib.check(_lib.lib().vitseg_op_wgrad_bf16(dYd.data_ptr(), Xd.data_ptr(), dW.data_ptr(), scratch.data_ptr(),
+                                               zeros.data_ptr(), M, N, K, _stream()))
+    assert (dW.cpu().double() - ref).abs().max().item() < 4e-7 * scale + 1e-5

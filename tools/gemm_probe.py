@@ -87,3 +87,38 @@ for name, N, K, epi in SHAPES:
     print(f"{name:18s} M={M} N={N} K={K}: p8 {best['p8'] * 1e6:7.1f} us {fl / best['p8'] / 1e12:7.1f} TF/s | old "
           f"{best['old'] * 1e6:7.1f} us {fl / best['old'] / 1e12:7.1f} | vendor plain {fl / best['vendor'] / 1e12:7.1f} | "
           f"max err p8 {err['p8']:.3e} old {err['old']:.3e} p8-old {same:.3e}", flush=True)
+
+
+# ---- weight gradients: dW[M_out, N_out] = dY^T X over the token rows (both operands token-major) ----
+print("weight gradients (T-form x T-form, split over the token rows):")
+Kt = M + a.batch
+zeros = torch.zeros(256, dtype=torch.uint8, device=dev)
+for name, Mo, No in [("dW fc2", 768, 3072), ("dW fc1", 3072, 768), ("dW o_proj", 768, 768), ("dW qkv", 2304, 768)]:
+    dY = torch.randn(Kt, Mo, device=dev).to(torch.bfloat16)
+    X = torch.randn(Kt, No, device=dev).to(torch.bfloat16)
+    dW = torch.empty(Mo, No, device=dev)
+    scratch = torch.empty(L.vitseg_op_wgrad_bf16_scratch_floats(Mo, No, Kt), device=dev)
+    fn = lambda: _lib.check(L.vitseg_op_wgrad_bf16(dY.data_ptr(), X.data_ptr(), dW.data_ptr(), scratch.data_ptr(),
+                                                   zeros.data_ptr(), Mo, No, Kt, st))
+    outs = {}
+    for label, env in (("p8", None), ("old", "1")):
+        if env:
+            os.environ["VITSEG_NO_P8"] = env
+        else:
+            os.environ.pop("VITSEG_NO_P8", None)
+        fn()
+        outs[label] = dW.clone()
+    ref = dY[:, :64].float().T @ X.float()
+    err = {k: float((v[:64] - ref).abs().max() / ref.abs().max()) for k, v in outs.items()}
+    fl = 2.0 * Mo * No * Kt
+    best = {"p8": 1e9, "old": 1e9, "vendor": 1e9}
+    for _ in range(a.rounds):
+        os.environ.pop("VITSEG_NO_P8", None)
+        best["p8"] = min(best["p8"], timed(fn))
+        os.environ["VITSEG_NO_P8"] = "1"
+        best["old"] = min(best["old"], timed(fn))
+        best["vendor"] = min(best["vendor"], timed(lambda: torch.matmul(dY.t(), X)))
+    os.environ.pop("VITSEG_NO_P8", None)
+    print(f"{name:18s} M={Mo} N={No} K={Kt}: p8 {best['p8'] * 1e6:7.1f} us {fl / best['p8'] / 1e12:7.1f} TF/s | old "
+          f"{best['old'] * 1e6:7.1f} us {fl / best['old'] / 1e12:7.1f} | vendor plain {fl / best['vendor'] / 1e12:7.1f} | "
+          f"rel err p8 {err['p8']:.2e} old {err['old']:.2e}", flush=True)

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visiontransformer_amd import _lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("op", choices=["linear", "attention", "layernorm", "linear_ex"])
+ap.add_argument("op", choices=["linear", "attention", "layernorm", "linear_ex", "wgrad"])
 ap.add_argument("--M", type=int, default=32800)
 ap.add_argument("--N", type=int, default=3072)
 ap.add_argument("--K", type=int, default=768)
@@ -29,7 +29,16 @@ a = ap.parse_args()
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 L = _lib.lib()
-if a.op == "linear_ex":   # 16-bit linear with every epilogue (0 bias, 1 GELU, 2 residual fp32, 5 dGELU), bf16
+if a.op == "wgrad":   # dW[M,N] = dY^T X over K token rows, bf16 operands token-major
+    dY = torch.randn(a.K, a.M, device=dev).to(torch.bfloat16)
+    X = torch.randn(a.K, a.N, device=dev).to(torch.bfloat16)
+    dW = torch.empty(a.M, a.N, device=dev)
+    zeros = torch.zeros(256, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(L.vitseg_op_wgrad_bf16_scratch_floats(a.M, a.N, a.K), device=dev)
+    run = lambda: _lib.check(L.vitseg_op_wgrad_bf16(dY.data_ptr(), X.data_ptr(), dW.data_ptr(), scratch.data_ptr(),
+                                                    zeros.data_ptr(), a.M, a.N, a.K, st))
+    work = 2.0 * a.M * a.N * a.K
+elif a.op == "linear_ex":   # 16-bit linear with every epilogue (0 bias, 1 GELU, 2 residual fp32, 5 dGELU), bf16
     A = torch.randn(a.M, a.K, device=dev).to(torch.bfloat16)
     W = (torch.randn(a.N, a.K, device=dev) * 0.05).to(torch.bfloat16)
     b = torch.randn(a.N, device=dev)

@@ -483,12 +483,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                 v[ps] = *(const f32x4*)&wl[row * 64 + c4];
                 if (EPI == EPI_RESADD || (EPI == EPI_DGELU && sizeof(T) == 4))
                     extra[ps] = *(const f32x4*)(p.R + (size_t)grow * p.ldc + gcol);
-                if (EPI == EPI_DGELU && sizeof(T) == 2) {  // bf16 training: the saved pre-activation is bf16
-                    const uint2 u = *(const uint2*)((const bf16_t*)p.R + (size_t)grow * p.ldc + gcol);
-                    extra[ps][0] = bf16_to_f32((unsigned short)u.x);
-                    extra[ps][1] = __uint_as_float(u.x & 0xffff0000u);
-                    extra[ps][2] = bf16_to_f32((unsigned short)u.y);
-                    extra[ps][3] = __uint_as_float(u.y & 0xffff0000u);
+                if constexpr (EPI == EPI_DGELU && sizeof(T) == 2) {  // 16-bit training: R = the saved gelu'(u), 16-bit
+                    const uint2 u = *(const uint2*)((const T*)p.R + (size_t)grow * p.ldc + gcol);
+                    extra[ps][0] = H16<T>::lo(u.x);
+                    extra[ps][1] = H16<T>::hi(u.x);
+                    extra[ps][2] = H16<T>::lo(u.y);
+                    extra[ps][3] = H16<T>::hi(u.y);
                 }
                 if (EPI == EPI_POS) extra[ps] = *(const f32x4*)(p.R + (size_t)(1 + grow % p.Np) * p.N + gcol);
             }
@@ -501,14 +501,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = v[ps][e] + bias4[e];
-                    if (EPI == EPI_GELU && p.aux) aux4[e] = x;
+                    // saved for the backward: fp32 keeps the pre-activation u, the 16-bit path keeps gelu'(u) itself
+                    // (the backward epilogue is then one multiply instead of an erf + exp per element)
+                    if (EPI == EPI_GELU && p.aux) aux4[e] = sizeof(T) == 4 ? x : gelu_erf_grad_fast(x);
                     if (EPI == EPI_GELU) x = (sizeof(T) == 4) ? gelu_erf(x) : gelu_erf_fast(x);
                     if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
                     if (EPI == EPI_RESADD && p.drop.thresh)
-                        x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow), gcol + e, p.drop.thresh)
+                        x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow + p.row_base), gcol + e, p.drop.thresh)
                                 ? x * p.drop.scale : 0.f;
                     if (EPI == EPI_RESADD || EPI == EPI_POS) x = extra[ps][e] + x;
-                    if (EPI == EPI_DGELU) x *= sizeof(T) == 4 ? gelu_erf_grad(extra[ps][e]) : gelu_erf_grad_fast(extra[ps][e]);
+                    if (EPI == EPI_DGELU) x *= sizeof(T) == 4 ? gelu_erf_grad(extra[ps][e]) : extra[ps][e];
                     v[ps][e] = x;
                 }
                 if (EPI == EPI_GELU && p.aux) {  // pre-activation, saved for the backward pass
@@ -1023,7 +1025,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_large_kernel(const GemmA
                 const int grow = min(m0 + wm * WROWS + half * 64 + row, p.M - 1);
                 extra[ps] = *(const f32x4*)(p.R + (size_t)grow * p.ldc + min(gcol, p.N - 4));
             }
-            if (EPI == EPI_DGELU) {  // training: R = the saved 16-bit pre-activation
+            if (EPI == EPI_DGELU) {  // training: R = the saved 16-bit gelu'(pre-activation)
                 const int grow = min(m0 + wm * WROWS + half * 64 + row, p.M - 1);
                 const uint2 u = *(const uint2*)((const T*)p.R + (size_t)grow * p.ldc + min(gcol, p.N - 4));
                 extra[ps][0] = H16<T>::lo(u.x);
@@ -1041,17 +1043,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_large_kernel(const GemmA
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = v[ps][e] + bias4[e];
-                    pre[e] = x;
+                    if (EPI == EPI_GELU && p.aux) pre[e] = gelu_erf_grad_fast(x);   // saved for the backward: gelu'(u)
                     if (EPI == EPI_GELU) x = gelu_erf_fast(x);
                     if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
                     if (EPI == EPI_RESADD && p.drop.thresh)
-                        x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow), gcol + e, p.drop.thresh)
+                        x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow + p.row_base), gcol + e, p.drop.thresh)
                                 ? x * p.drop.scale : 0.f;
                     if (EPI == EPI_RESADD) x = extra[ps][e] + x;
-                    if (EPI == EPI_DGELU) x *= gelu_erf_grad_fast(extra[ps][e]);
+                    if (EPI == EPI_DGELU) x *= extra[ps][e];
                     v[ps][e] = x;
                 }
-                if (EPI == EPI_GELU && p.aux && grow < p.M) {  // training: keep the pre-activation for the backward
+                if (EPI == EPI_GELU && p.aux && grow < p.M) {  // training: keep gelu'(pre-activation) for the backward
                     uint2 h;
                     h.x = H16<T>::pack2(pre[0], pre[1]);
                     h.y = H16<T>::pack2(pre[2], pre[3]);
@@ -1106,6 +1108,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
         ((f32x4*)out)[i] = acc;
     }
+}
+
+int launch_splitk_reduce(const float* partial, float* out, size_t n4, int splits, hipStream_t s) {
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, out, n4, splits);
+    VITSEG_LAUNCH_CHECK("splitk_reduce");
+    return VITSEG_OK;
 }
 
 int wgrad_splits(int M, int N, int K) {
@@ -1172,7 +1181,34 @@ int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
                      a.ldc);
     // the 256x128 / 3-stage kernel and the 128x128 / 2-stage kernel measure within a few % of each other on the
     // model's shapes (both ~790 TF/s asymptote); the large one is used where its deeper prefetch helps: long K
-    if (amode == A_PLAIN && gemm_p8_applies(a, epi)) return launch_gemm_p8(a, epi, s, sizeof(T) == 2 && std::is_same<T, f16_t>::value);
+    if (amode == A_PLAIN && gemm_p8_applies(a, epi)) {
+        // persistent 256x256 kernel (gemm_p8.hip).  A ragged last row tile would cost every CU a whole extra round
+        // (M = 65 600: 257 x 12 tiles over 256 CUs = 13 rounds for 12.05 rounds of work), so up to 128 trailing rows
+        // (the CLS rows) go through the 128x128 kernel as a second, tiny launch with the same epilogue.
+        const int tail = a.M % 256;
+        if (tail == 0 || tail > 128) return launch_gemm_p8(a, epi, s, std::is_same<T, f16_t>::value);
+        GemmArgs body = a, t = a;
+        body.M = a.M - tail;
+        if (int rc = launch_gemm_p8(body, epi, s, std::is_same<T, f16_t>::value)) return rc;
+        const size_t ro = (size_t)body.M;
+        t.M = tail;
+        t.row_base = a.row_base + body.M;
+        t.A = (const T*)a.A + ro * a.lda;
+        if (a.aux) t.aux = (T*)a.aux + ro * a.ldc;
+        if (epi == EPI_RESADD) {
+            t.R = a.R + ro * a.ldc;
+            t.C = (float*)a.C + ro * a.ldc;
+        } else {
+            if (a.R) t.R = (const float*)((const T*)a.R + ro * a.ldc);   // EPI_DGELU: 16-bit operand
+            t.C = (T*)a.C + ro * a.ldc;
+        }
+        switch (epi) {
+            case EPI_BIAS: return launch_one<T, T, A_PLAIN, EPI_BIAS>(t, s);
+            case EPI_GELU: return launch_one<T, T, A_PLAIN, EPI_GELU>(t, s);
+            case EPI_DGELU: return launch_one<T, T, A_PLAIN, EPI_DGELU>(t, s);
+            default: return launch_one<T, float, A_PLAIN, EPI_RESADD>(t, s);
+        }
+    }
     const char* force = getenv("VITSEG_BF16_TILES");  // "large" / "xl" / "4w" (256x256, 4 waves) / "small" for experiments
     const bool w4 = force && force[0] == '4';
     const bool xl = force ? force[0] == 'x' : (a.M >= 8192 && a.N >= 2048);
@@ -1330,6 +1366,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tt_kernel(const GemmArgs p) 
 int launch_wgrad_bf16_tt(GemmArgs a, float* scratch, hipStream_t s) {
     VITSEG_CHECK_ARG(a.M % 8 == 0 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc == a.N && a.zeros,
                      VITSEG_ESHAPE, "wgrad_bf16_tt: M, N and the leading dimensions must be multiples of 8");
+    if (wgrad_p8_applies(a)) return launch_wgrad_p8(a, scratch, s);   // 256x256 tiles, 8-phase stream (gemm_p8.hip)
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     int splits = 1024 / tiles;  // <= 2 whole rounds of 512 resident blocks
     const int ksteps = (a.K + 63) / 64;
@@ -1386,7 +1423,12 @@ size_t wgrad_bf16_scratch_floats(int M, int N, int K) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits = 1024 / tiles;  // <= 2 whole rounds of 512 resident blocks
     if (splits > K / 64 / 4) splits = K / 64 / 4;
-    return (size_t)(splits < 1 ? 1 : splits) * M * N;
+    if (splits < 1) splits = 1;
+    if (M % 256 == 0 && N % 256 == 0) {   // the 8-phase kernel's slicing (wgrad_p8_splits), whichever is larger
+        const int sp8 = wgrad_p8_splits(M, N, K);
+        if (sp8 > splits) splits = sp8;
+    }
+    return (size_t)splits * M * N;
 }
 
 }  // namespace vitseg

@@ -19,6 +19,11 @@
 //     consecutive output columns of one row, which it parks as one 16-byte LDS write in a wave-private 4 KiB
 //     staging slab (outside the ring, so the operand stream keeps flowing); the slab is read back row-wise for
 //     the bias / GELU / residual / dropout arithmetic and whole-line global stores.
+// TT = 1 is the weight-gradient form  C[M,N] = sum_k A[k][m] W[k][n]  (dW = dY^T X: both operands lie [token][column],
+// the reduction runs over the token rows, split over `splitk` slices that write fp32 partial tiles): the same ring,
+// phases and stream, but a half-tile is [64 tokens][128 columns] (256-byte rows, 16-byte chunk c of row r stored at
+// c ^ (((r & 3) << 2) | ((r >> 2) & 3))) and the MFMA operands are gathered DOWN the columns with ds_read_b64_tr_b16
+// (two per fragment; both operands see the same token order, so the products pair up); no transposed copies exist.
 // Roofline: MFMA bf16/f16 dense 2.5 PFLOP/s; algorithmic work 2 M N K per launch.
 #include <stdlib.h>
 
@@ -48,15 +53,18 @@ template <> struct Mfma16<f16_t> {
 };
 
 struct TileCoord {
-    int m0, n0;
+    int m0, n0, split;
 };
-// Logical tile order: column groups of GN tiles, row panels marching inside a group; the 32 blocks of one XCD
-// (blockIdx % 8 equal) take 32 consecutive logical tiles of every round = an (8 x 4)-ish patch that shares operand
-// panels through that XCD's L2.
-__device__ __forceinline__ TileCoord tile_coord(int round, int tiles_m, int tiles_n, int gn) {
+// Logical order of this block's `round`-th work item: the 32 blocks of one XCD (blockIdx % 8 equal) take 32 consecutive
+// logical items of every round, so that they share operand panels through that XCD's L2.
+__device__ __forceinline__ int logical_item(int round, int nitems) {
     const int first = round * (int)gridDim.x;
-    const int live = min((int)gridDim.x, tiles_m * tiles_n - first);   // blocks that still have a tile in this round
-    const int t = first + xcd_remap(min((int)blockIdx.x, live - 1), live);
+    const int live = min((int)gridDim.x, nitems - first);   // blocks that still have an item in this round
+    return first + xcd_remap(min((int)blockIdx.x, live - 1), live);
+}
+// NT: column groups of GN tiles, row panels marching inside a group (32 consecutive = an (8 x 4)-ish patch of tiles).
+__device__ __forceinline__ TileCoord tile_coord(int round, int tiles_m, int tiles_n, int gn) {
+    const int t = logical_item(round, tiles_m * tiles_n);
     const int gsz = tiles_m * gn, ngroups = (tiles_n + gn - 1) / gn;
     const int grp = min(t / gsz, ngroups - 1);
     const int rem = t - grp * gsz;
@@ -65,10 +73,23 @@ __device__ __forceinline__ TileCoord tile_coord(int round, int tiles_m, int tile
     const int tm = rem / gcols;
     c.m0 = tm * PT;
     c.n0 = (grp * gn + rem - tm * gcols) * PT;
+    c.split = 0;
+    return c;
+}
+// TT: split-major -- the blocks that run together reduce the same token range into different output tiles
+__device__ __forceinline__ TileCoord item_coord_tt(int round, int tiles_m, int tiles_n, int splits) {
+    const int nt = tiles_m * tiles_n;
+    const int t = logical_item(round, nt * splits);
+    TileCoord c;
+    c.split = t / nt;
+    const int rem = t - c.split * nt;
+    const int tm = rem / tiles_n;
+    c.m0 = tm * PT;
+    c.n0 = (rem - tm * tiles_n) * PT;
     return c;
 }
 
-template <typename T, typename OutT, int EPI>
+template <typename T, typename OutT, int EPI, int TT>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ring | per-wave staging (ONE array: see the guide)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -77,12 +98,18 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
     const int l15 = lane & 15, lq = lane >> 4;
 
     const int tiles_m = (p.M + PT - 1) / PT, tiles_n = p.N / PT;
-    const int ntiles = tiles_m * tiles_n;
+    const int splits = TT ? max(p.splitk, 1) : 1;
+    const int ntiles = tiles_m * tiles_n * splits;          // work items
     const int gn = (tiles_n % 4 == 0) ? 4 : (tiles_n % 3 == 0 ? 3 : (tiles_n >= 4 ? 4 : tiles_n));
-    const int KT = p.K / 64;
-    // this block's tiles: blockIdx.x, blockIdx.x + gridDim.x, ...
+    // K steps (64 deep) per item, always even: NT K / 64 (K % 128 == 0); TT an even share of the token rows per slice
+    // (rows beyond K are out of the buffer range and read as zeros)
+    const int KT = TT ? ((((p.K + 63) / 64 + splits - 1) / splits + 1) & ~1) : p.K / 64;
+    // this block's items: blockIdx.x, blockIdx.x + gridDim.x, ...
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total_k = my_tiles * KT;            // K steps this block walks
+    auto coord = [&](int round) {
+        return TT ? item_coord_tt(round, tiles_m, tiles_n, splits) : tile_coord(round, tiles_m, tiles_n, gn);
+    };
 
     // ---- DMA side: per-lane byte offsets inside a tile (constant for the whole kernel) ----
     unsigned voffA[2][2], voffW[2][2];
@@ -90,16 +117,24 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
-            const int i = 16 * wave + 8 * pc + (lane >> 3);          // row inside the half-tile
-            const int cpos = (lane & 7) ^ ((i >> 1) & 7);            // logical chunk stored at position lane & 7
-            const int ra = (i >> 6) * 128 + h * 64 + (i & 63);
-            const int rw = (i >> 5) * 64 + h * 32 + (i & 31);
-            voffA[h][pc] = (unsigned)ra * (unsigned)p.lda * 2u + cpos * 16;
-            voffW[h][pc] = (unsigned)rw * (unsigned)p.ldw * 2u + cpos * 16;
+            if (TT) {   // piece = 4 token rows x 256 B; half h = columns [128 h, 128 h + 128) of the tile
+                const int r = 4 * (2 * wave + pc) + (lane >> 4);
+                const int ch = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+                voffA[h][pc] = (unsigned)r * (unsigned)p.lda * 2u + (h * 128 + ch * 8) * 2;
+                voffW[h][pc] = (unsigned)r * (unsigned)p.ldw * 2u + (h * 128 + ch * 8) * 2;
+            } else {
+                const int i = 16 * wave + 8 * pc + (lane >> 3);          // row inside the half-tile
+                const int cpos = (lane & 7) ^ ((i >> 1) & 7);            // logical chunk stored at position lane & 7
+                const int ra = (i >> 6) * 128 + h * 64 + (i & 63);
+                const int rw = (i >> 5) * 64 + h * 32 + (i & 31);
+                voffA[h][pc] = (unsigned)ra * (unsigned)p.lda * 2u + cpos * 16;
+                voffW[h][pc] = (unsigned)rw * (unsigned)p.ldw * 2u + cpos * 16;
+            }
         }
     // issue side: two cursors, because one K step G issues halves B1 / A1 of step G + 1 (cursor 0, phases 0 and 1) and
     // A0 / B0 of step G + 2 (cursor 1, phases 2 and 3); both advance once per K step.  A cursor is a pair of buffer
-    // descriptors rebased to the tile (rows beyond M are out of range and read as zeros) plus the K byte offset.
+    // descriptors rebased to the tile (NT: rows beyond M; TT: token rows beyond K are out of range and read as zeros)
+    // plus the K byte offset.
     // The DMA is issued from inline asm on purpose: hipcc then keeps its ordinary exact vmcnt bookkeeping for the
     // epilogue's loads and stores (with an LDS-DMA builtin in the kernel it waits vmcnt(0) before every use of a ds_read
     // or global-load result, which serialises the epilogue store by store); the ring is ordered by hand-counted waits.
@@ -107,42 +142,71 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
     struct Cursor {
         i32x4 a, w;       // raw buffer descriptors {base lo, base hi, num_records, flags}
         unsigned soff;    // K byte offset inside the tile's rows
-        int ts, kt;       // tile sequence number of this block, K step inside the tile
+        int ts, kt;       // item sequence number of this block, K step inside the item
+        int m0, n0, tok0; // TT: tile origin and first token row of the item
     };
     Cursor cur0, cur1;
-    auto make_rsrc = [](const void* base, size_t bytes) {
+    auto make_rsrc = [](const void* base, long long bytes) {   // (once per tile; the per-step path is 32-bit, below)
         const unsigned long long b = (unsigned long long)base;
         i32x4 r;
         r[0] = (int)(unsigned)b;
         r[1] = (int)(unsigned)((b >> 32) & 0xffffu);                       // stride 0
-        r[2] = (int)(unsigned)(bytes < 0x7fffffffull ? bytes : 0x7fffffffull);
+        r[2] = (int)(unsigned)(bytes <= 0 ? 0 : (bytes < 0x7fffffffll ? bytes : 0x7fffffffll));
         r[3] = 0x00020000;
         return r;
     };
+    // TT: the descriptors follow the token rows of the K step.  Everything per step is 32-bit scalar arithmetic (a
+    // 64-bit product or division here costs more than the 256-cycle phase it sits in): base += 64 rows, and
+    // num_records = bytes from the base to the end of the matrix, saturated, 0 once the step lies beyond the last row.
+    const unsigned stepA = 64u * (unsigned)p.lda * 2u, stepW = 64u * (unsigned)p.ldw * 2u;
+    const int capA = (int)(0x7fffffffu / ((unsigned)p.lda * 2u)), capW = (int)(0x7fffffffu / ((unsigned)p.ldw * 2u));
+    auto set_records_tt = [&](Cursor& c) {
+        const int left = c.ts < my_tiles ? p.K - (c.tok0 + c.kt * 64) : 0;     // token rows from this step to the end
+        c.a[2] = left <= 0 ? 0 : (left >= capA ? 0x7fffffff : left * p.lda * 2 - c.m0 * 2);
+        c.w[2] = left <= 0 ? 0 : (left >= capW ? 0x7fffffff : left * p.ldw * 2 - c.n0 * 2);
+    };
+    auto add_base = [](i32x4& r, unsigned bytes) {
+        const unsigned lo = (unsigned)r[0] + bytes;
+        r[1] += lo < bytes ? 1 : 0;
+        r[0] = (int)lo;
+    };
     auto set_tile = [&](Cursor& c) {
         if (c.ts < my_tiles) {
-            const TileCoord tc = tile_coord(c.ts, tiles_m, tiles_n, gn);
-            c.a = make_rsrc((const T*)p.A + (size_t)tc.m0 * p.lda, (size_t)(p.M - tc.m0) * p.lda * 2);
-            c.w = make_rsrc((const T*)p.W + (size_t)tc.n0 * p.ldw, (size_t)PT * p.ldw * 2);
+            const TileCoord tc = coord(c.ts);
+            if (TT) {
+                c.m0 = tc.m0; c.n0 = tc.n0; c.tok0 = tc.split * KT * 64;
+                const long long tok = (long long)c.tok0 + (long long)c.kt * 64;
+                c.a = make_rsrc((const T*)p.A + tok * p.lda + c.m0, 0);
+                c.w = make_rsrc((const T*)p.W + tok * p.ldw + c.n0, 0);
+            } else {
+                c.a = make_rsrc((const T*)p.A + (size_t)tc.m0 * p.lda, (long long)(p.M - tc.m0) * p.lda * 2);
+                c.w = make_rsrc((const T*)p.W + (size_t)tc.n0 * p.ldw, (long long)PT * p.ldw * 2);
+            }
         } else {                               // past the end: zero-record descriptors, the DMA moves nothing
+            c.m0 = c.n0 = c.tok0 = 0;
             c.a = make_rsrc(p.A, 0);
             c.w = make_rsrc(p.W, 0);
         }
+        if (TT) set_records_tt(c);
     };
     auto set_cursor = [&](Cursor& c, int gstep) {   // gstep: index of the K step in this block's stream
         c.ts = gstep / KT;
         c.kt = gstep - c.ts * KT;
-        c.soff = (unsigned)c.kt * 128u;
+        c.soff = TT ? 0u : (unsigned)c.kt * 128u;
         set_tile(c);
     };
     auto advance = [&](Cursor& c) {                 // next K step of the stream
         ++c.kt;
-        c.soff += 128u;
+        if (!TT) c.soff += 128u;
         if (c.kt == KT) {
             c.kt = 0;
             c.soff = 0;
             ++c.ts;
             set_tile(c);
+        } else if (TT) {
+            add_base(c.a, stepA);
+            add_base(c.w, stepW);
+            set_records_tt(c);
         }
     };
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -162,26 +226,56 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
     // ---- fragment side ----
     const int sw = l15 >> 1;
     int a_rd[2], b_rd[2];
+    if (TT) {
+        // transposed gather: lane = 16 g + 4 q + p reads 4 tokens (8 g + 4 s + q is ITS address row) x 16 columns per
+        // ds_read_b64_tr_b16; a_rd[s] / b_rd[s] = byte offset of (m|n tile 0, k step 0), tile t at ^ (t << 5)
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        a_rd[ks] = (wr * 64 + l15) * 128 + (((4 * ks + lq) ^ sw) << 4);
-        b_rd[ks] = (wc * 32 + l15) * 128 + (((4 * ks + lq) ^ sw) << 4);
+        for (int sI = 0; sI < 2; ++sI) {
+            const int row = 8 * g + 4 * sI + q;
+            const int f = (q << 2) | ((2 * g + sI) & 3);
+            a_rd[sI] = row * 256 + ((((wr << 3) | (pp >> 1)) ^ f) << 4) + (pp & 1) * 8;
+            b_rd[sI] = row * 256 + ((((wc << 2) | (pp >> 1)) ^ f) << 4) + (pp & 1) * 8;
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            a_rd[ks] = (wr * 64 + l15) * 128 + (((4 * ks + lq) ^ sw) << 4);
+            b_rd[ks] = (wc * 32 + l15) * 128 + (((4 * ks + lq) ^ sw) << 4);
+        }
     }
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    auto tr_frag = [&](int region, int off0, int off1, int tile, int ks) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(lds + region * HALF_BYTES + ks * 8192 + (off0 ^ (tile << 5))));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(lds + region * HALF_BYTES + ks * 8192 + (off1 ^ (tile << 5))));
+        const bf16x8 fr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return fr;
+    };
     bf16x8 xa[4][2];          // activation fragments of the current A-half: [m tile][k step]
     bf16x8 wx[2][2], wy[2][2];  // weight fragments of the two B-halves (roles alternate per K step)
     auto read_a = [&](int region) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                xa[mt][ks] = *(const bf16x8*)(lds + region * HALF_BYTES + mt * 2048 + a_rd[ks]);
+            for (int ks = 0; ks < 2; ++ks) {
+                if (TT)
+                    xa[mt][ks] = tr_frag(region, a_rd[0], a_rd[1], mt, ks);   // m tile t = chunks 2 t, 2 t + 1: ^ (t << 5)
+                else
+                    xa[mt][ks] = *(const bf16x8*)(lds + region * HALF_BYTES + mt * 2048 + a_rd[ks]);
+            }
     };
     auto read_b = [&](bf16x8 (&w)[2][2], int region) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                w[nt][ks] = *(const bf16x8*)(lds + region * HALF_BYTES + nt * 2048 + b_rd[ks]);
+            for (int ks = 0; ks < 2; ++ks) {
+                if (TT)
+                    w[nt][ks] = tr_frag(region, b_rd[0], b_rd[1], nt, ks);
+                else
+                    w[nt][ks] = *(const bf16x8*)(lds + region * HALF_BYTES + nt * 2048 + b_rd[ks]);
+            }
     };
     f32x4 acc[8][4];          // [m tile][n tile]: rows n = 4 lq + r, column m = l15 (C transposed)
     auto zero_acc = [&]() {
@@ -213,17 +307,19 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
     float* stage = (float*)(lds + RING_BYTES + wave * STAGE_BYTES);
     auto epilogue = [&](const TileCoord tc) {
         constexpr bool OUT16 = sizeof(OutT) == 2;
-        const int gcol0 = tc.n0 + wc * 64;
         // row side: OUT16: lane -> rows (lane >> 3) + 8 i, 8 columns 8 (lane & 7); fp32: rows (lane >> 4) + 4 i, 4 columns
         constexpr int CPL = OUT16 ? 8 : 4;                 // columns per lane
         constexpr int LPR = 64 / CPL;                      // lanes per row
         constexpr int RPI = 64 / LPR;                      // rows per instruction
-        const int rrow = lane / LPR, rcol = (lane % LPR) * CPL;
+        const int rrow = lane / LPR, rcol = (lane % LPR) * CPL;   // rcol: column inside the wave's 64-column slab
+        // global column of slab column rcol: NT the wave owns 64 consecutive columns; TT two runs of 32 (one per B-half)
+        const int gcol = TT ? tc.n0 + (rcol >> 5) * 128 + wc * 32 + (rcol & 31) : tc.n0 + wc * 64 + rcol;
+        OutT* Cbase = (OutT*)p.C + (TT ? (size_t)tc.split * p.split_stride : 0);
         float bias_r[CPL];
 #pragma unroll
         for (int c4 = 0; c4 < CPL / 4; ++c4) {
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) b4 = *(const f32x4*)(p.bias + gcol0 + rcol + 4 * c4);
+            if (p.bias) b4 = *(const f32x4*)(p.bias + gcol + 4 * c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 bias_r[c4 * 4 + e] = b4[e];
@@ -232,13 +328,16 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
         }
         constexpr int NI = 16 / RPI;                       // row groups per 16-row slab
         constexpr bool HAS_EXTRA = EPI == EPI_RESADD || EPI == EPI_DGELU;
-        // operand of the epilogue arithmetic (residual rows / saved pre-activation), fetched ONE slab ahead: vmcnt retires
+        // operand of the epilogue arithmetic (residual rows / saved GELU derivative), fetched ONE slab ahead: vmcnt retires
         // in issue order, so a load issued after the previous slab's stores could only be waited for together with them
         float extra[2][NI][CPL];
-        auto row_of = [&](int mt, int i) { return tc.m0 + wr * 128 + mt * 16 + rrow + RPI * i; };
+        // m tile mt = (A-half mt >> 2, tile mt & 3 inside it): NT halves interleave per wave row, TT halves are 128-row runs
+        auto row_of = [&](int mt, int i) {
+            return tc.m0 + (TT ? (mt >> 2) * 128 + wr * 64 + (mt & 3) * 16 : wr * 128 + mt * 16) + rrow + RPI * i;
+        };
         auto off_of = [&](int mt, int i) {
             const int g = row_of(mt, i);
-            return (size_t)(g < p.M ? g : 0) * p.ldc + gcol0 + rcol;
+            return (size_t)(g < p.M ? g : 0) * p.ldc + gcol;
         };
         auto load_extra = [&](int buf, int mt) {
 #pragma unroll
@@ -248,7 +347,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) extra[buf][i][e] = r4[e];
                 }
-                if (EPI == EPI_DGELU) {   // R = the saved 16-bit pre-activation
+                if (EPI == EPI_DGELU) {   // R = the saved 16-bit gelu'(pre-activation)
                     const uint4 u = *(const uint4*)((const T*)p.R + off_of(mt, i));
                     const unsigned uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -284,17 +383,17 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
             for (int i = 0; i < NI; ++i) {
                 const int grow = row_of(mt, i);
                 const size_t o = off_of(mt, i);
-                float pre[CPL];
+                float pre[CPL] = {};
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) {
                     float x = v[i][e] + bias_r[e];
-                    pre[e] = x;
+                    if (EPI == EPI_GELU && p.aux) pre[e] = gelu_erf_grad_fast(x);   // saved for the backward: gelu'(u)
                     if (EPI == EPI_GELU) x = gelu_erf_fast(x);
                     if (EPI == EPI_RESADD && p.drop.thresh)
-                        x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow), gcol0 + rcol + e, p.drop.thresh)
+                        x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow + p.row_base), gcol + e, p.drop.thresh)
                                 ? x * p.drop.scale : 0.f;
                     if (EPI == EPI_RESADD) x = extra[mt & 1][i][e] + x;
-                    if (EPI == EPI_DGELU) x *= gelu_erf_grad_fast(extra[mt & 1][i][e]);
+                    if (EPI == EPI_DGELU) x *= extra[mt & 1][i][e];
                     v[i][e] = x;
                 }
                 if constexpr (OUT16) {
@@ -305,10 +404,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
                     ha.z = H16<T>::pack2(pre[4], pre[5]); ha.w = H16<T>::pack2(pre[6], pre[7]);
                     if (grow < p.M) {
                         if (EPI == EPI_GELU && p.aux) *(uint4*)((T*)p.aux + o) = ha;
-                        *(uint4*)((OutT*)p.C + o) = h;
+                        *(uint4*)(Cbase + o) = h;
                     }
                 } else {
-                    if (grow < p.M) *(f32x4*)((float*)p.C + o) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+                    if (grow < p.M) *(f32x4*)((float*)Cbase + o) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
                 }
             }
         }
@@ -329,7 +428,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
     set_cursor(cur1, 2);
     if (wr == 1) P8_BAR();                    // wave row 1 runs one barrier interval behind wave row 0
 
-    TileCoord tc_cur = tile_coord(0, tiles_m, tiles_n, gn);
+    TileCoord tc_cur = coord(0);
     int kt_in_tile = 0, tile_seq = 0;
     // one K step; `s` = parity of the step, (w0, w1) = (fragments holding this step's B0, the other buffer)
 #define P8_KSTEP(s, w0, w1, G)                                                                       \
@@ -377,7 +476,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
             zero_acc();
             kt_in_tile = 0;
             ++tile_seq;
-            if (tile_seq < my_tiles) tc_cur = tile_coord(tile_seq, tiles_m, tiles_n, gn);
+            if (tile_seq < my_tiles) tc_cur = coord(tile_seq);
         }
     }
     if (wr == 0) P8_BAR();
@@ -396,36 +495,41 @@ bool gemm_p8_applies(const GemmArgs& a, int epi) {
            (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESADD || epi == EPI_DGELU);
 }
 
-template <typename T, typename OutT, int EPI>
-static int launch_p8_one(GemmArgs a, hipStream_t s) {
-    if (a.ldw == 0) a.ldw = a.K;
-    const int tiles = ((a.M + PT - 1) / PT) * (a.N / PT);
+static int p8_num_cus() {
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hip_fail(hipGetLastError(), "device properties");
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    return ncu;
+}
+
+template <typename T, typename OutT, int EPI, int TT>
+static int launch_p8_one(GemmArgs a, int items, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_p8_kernel<T, OutT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_p8_kernel<T, OutT, EPI, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_p8)");
         attr_set = true;
     }
-    const int grid = tiles < ncu ? tiles : ncu;
-    hipLaunchKernelGGL((gemm_p8_kernel<T, OutT, EPI>), dim3(grid), dim3(512), P8_LDS, s, a);
+    const int ncu = p8_num_cus();
+    const int grid = items < ncu ? items : ncu;
+    hipLaunchKernelGGL((gemm_p8_kernel<T, OutT, EPI, TT>), dim3(grid), dim3(512), P8_LDS, s, a);
     VITSEG_LAUNCH_CHECK("gemm_p8");
     return VITSEG_OK;
 }
 
 template <typename T>
-static int launch_p8_t(const GemmArgs& a, int epi, hipStream_t s) {
+static int launch_p8_t(GemmArgs a, int epi, hipStream_t s) {
+    if (a.ldw == 0) a.ldw = a.K;
+    const int tiles = ((a.M + PT - 1) / PT) * (a.N / PT);
     switch (epi) {
-        case EPI_BIAS: return launch_p8_one<T, T, EPI_BIAS>(a, s);
-        case EPI_GELU: return launch_p8_one<T, T, EPI_GELU>(a, s);
-        case EPI_DGELU: return launch_p8_one<T, T, EPI_DGELU>(a, s);
-        case EPI_RESADD: return launch_p8_one<T, float, EPI_RESADD>(a, s);
+        case EPI_BIAS: return launch_p8_one<T, T, EPI_BIAS, 0>(a, tiles, s);
+        case EPI_GELU: return launch_p8_one<T, T, EPI_GELU, 0>(a, tiles, s);
+        case EPI_DGELU: return launch_p8_one<T, T, EPI_DGELU, 0>(a, tiles, s);
+        case EPI_RESADD: return launch_p8_one<T, float, EPI_RESADD, 0>(a, tiles, s);
     }
     set_error("gemm_p8: unsupported epilogue %d", epi);
     return VITSEG_EINVAL;
@@ -433,6 +537,35 @@ static int launch_p8_t(const GemmArgs& a, int epi, hipStream_t s) {
 
 int launch_gemm_p8(const GemmArgs& a, int epi, hipStream_t s, bool f16) {
     return f16 ? launch_p8_t<f16_t>(a, epi, s) : launch_p8_t<bf16_t>(a, epi, s);
+}
+
+// ---- weight gradients:  dW[M,N] (fp32, dense) = A^T . W,  A = [K tokens][M], W = [K tokens][N] bf16 row-major ----
+// Work items = output tiles x K slices, as close to one per CU as an even number of 64-token steps per slice allows;
+// each slice stores its fp32 partial tile and splitk_reduce sums the slices in a fixed order (deterministic).
+bool wgrad_p8_applies(const GemmArgs& a) {
+    if (getenv("VITSEG_NO_P8")) return false;
+    return a.M % PT == 0 && a.N % PT == 0 && a.K >= 1024 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc == a.N &&
+           (size_t)a.K * a.lda * 2 < 0x7fffffffull && (size_t)a.K * a.ldw * 2 < 0x7fffffffull;
+}
+int wgrad_p8_splits(int M, int N, int K) {
+    const int tiles = (M / PT) * (N / PT);
+    int splits = p8_num_cus() / tiles;
+    const int ksteps = (K + 63) / 64;
+    if (splits > ksteps / 8) splits = ksteps / 8;   // >= 8 K steps per slice
+    return splits < 1 ? 1 : splits;
+}
+int launch_wgrad_p8(GemmArgs a, float* scratch, hipStream_t s) {
+    const int tiles = (a.M / PT) * (a.N / PT);
+    const int splits = wgrad_p8_splits(a.M, a.N, a.K);
+    VITSEG_CHECK_ARG(splits == 1 || scratch, VITSEG_EINVAL, "wgrad_p8: split-K needs scratch");
+    a.splitk = splits;
+    a.split_stride = (size_t)a.M * a.N;
+    a.bias = nullptr;
+    float* out = (float*)a.C;
+    if (splits > 1) a.C = scratch;
+    if (int rc = launch_p8_one<bf16_t, float, EPI_BIAS, 1>(a, tiles * splits, s)) return rc;
+    if (splits > 1) return launch_splitk_reduce(scratch, out, (size_t)a.M * a.N / 4, splits, s);
+    return VITSEG_OK;
 }
 
 }  // namespace vitseg

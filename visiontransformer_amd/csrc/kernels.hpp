@@ -45,6 +45,7 @@ struct GemmArgs {
     int thin_rows;
     int gn;               // column-group width of the tile order (0 = pick from K; VITSEG_GN overrides for experiments)
     DropArgs drop;        // EPI_RESADD: C = R + dropout(acc + bias)   (hidden dropout, modeling_vit.py:276,283)
+    int row_base;         // added to the row index of the dropout hash when a launch covers rows [row_base, row_base + M)
 };
 
 // x3: fp32 operands split into half pairs while staged, 3 fp16 MFMAs per product (fp32-grade results, gemm.hip X3)
@@ -72,6 +73,11 @@ int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s, bool 
 // persistent 8-phase 256x256 kernel for the large plain linear layers (gemm_p8.hip); `applies` = shape / alignment test
 bool gemm_p8_applies(const GemmArgs& a, int epi);
 int launch_gemm_p8(const GemmArgs& a, int epi, hipStream_t s, bool f16);
+// the same kernel in its T-form x T-form guise (weight gradients, split over the token rows)
+bool wgrad_p8_applies(const GemmArgs& a);
+int wgrad_p8_splits(int M, int N, int K);
+int launch_wgrad_p8(GemmArgs a, float* scratch, hipStream_t s);
+int launch_splitk_reduce(const float* partial, float* out, size_t n4, int splits, hipStream_t s);
 
 // LayerNorm over the last dim (a4); out_fmt: 0 fp32 output, 1 bf16, 2 IEEE half.
 int launch_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int D, float eps,

@@ -420,6 +420,18 @@ int vitseg_op_linear_h16_ex(const void* A, const void* Wt, const float* bias, co
     return launch_gemm_bf16(g, A_PLAIN, epilogue, (hipStream_t)stream, f16 != 0);
 }
 
+size_t vitseg_op_wgrad_bf16_scratch_floats(int M, int N, int K) { return wgrad_bf16_scratch_floats(M, N, K); }
+
+int vitseg_op_wgrad_bf16(const void* dY, const void* X, float* dW, float* scratch, const void* zeros, int M, int N, int K,
+                         void* stream) {
+    VITSEG_CHECK_ARG(dY && X && dW && zeros, VITSEG_EINVAL, "wgrad_bf16: null pointer");
+    GemmArgs g{};
+    g.A = dY; g.W = X; g.C = dW;
+    g.M = M; g.N = N; g.K = K; g.lda = M; g.ldw = N; g.ldc = N;
+    g.zeros = zeros;
+    return launch_wgrad_bf16_tt(g, scratch, (hipStream_t)stream);
+}
+
 int vitseg_op_gemm_f32(const float* A, const float* Wt, const float* R, float* C, int M, int N, int K, int ta, int tb,
                        int epilogue, void* stream) {
     VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "gemm: null pointer");

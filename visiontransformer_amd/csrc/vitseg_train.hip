@@ -103,8 +103,10 @@ TrainPlan make_train_plan(const Shape& s, int B, int precision) {
         mx(wgrad_bf16_scratch_floats(s.I, s.D, (int)p.Kpad));
         mx(wgrad_bf16_scratch_floats(s.D, s.D, (int)p.Kpad));
         mx(wgrad_bf16_scratch_floats(3 * s.D, s.D, (int)p.Kpad));
-        mx(wgrad_scratch_floats(MID, 9 * s.D, (int)p.Mp));  // the head and patch wgrads stay fp32
+        mx(wgrad_scratch_floats(MID, 9 * s.D, (int)p.Mp));  // head and patch weight gradients: fp32 or bf16 slicing
         mx(wgrad_scratch_floats(s.D, s.Kp, (int)p.Mp));
+        mx(wgrad_bf16_scratch_floats(MID, 9 * s.D, (int)p.Mp));
+        mx(wgrad_bf16_scratch_floats(s.D, s.Kp, (int)p.Mp));
         mx(thin_scratch_floats(s.I > 3 * s.D ? s.I : 3 * s.D));   // also the split-K partials of the CLS rows (dgrad, qkv)
         p.wscratch = take(w * 4);
         p.wscratch_floats = w;
