@@ -453,3 +453,52 @@ def test_training_step_vitb_width_512_dropout_masks_injected(precision):
     ref.backward()
     assert abs(float(loss.detach()) - float(ref)) < (2e-6 if precision == "fp32" else 5e-3)
     _grad_check(cfg, m.arena.grad, leaf, precision)
+
+
+@pytest.mark.parametrize("B,Np,A,p", [(2, 256, 2, 0.0), (1, 1024, 2, 0.0), (2, 196, 3, 0.0), (1, 64, 1, 0.0), (2, 100, 2, 0.0),
+                                      (1, 1024, 1, 0.1), (2, 196, 2, 0.1), (2, 256, 3, 0.1)])
+def test_attention_backward_bf16(B, Np, A, p):
+    """bf16 attention core, forward (ctx, log-sum-exp) + backward (dq | dk | dv), with and without the attention-probability
+    dropout (the kernels' counter-based mask regenerated in numpy and injected into the reference), against fp64 autograd
+    on the same bf16-rounded inputs.  Whole-tile (Np % 128 == 0) and ragged shapes; the CLS token takes the vector paths."""
+    from dropout_ref import Masks
+    D, Mt, N = 64 * A, B * Np + B, Np + 1
+    qkv = _rand(Mt, 3 * D, seed=Np + A, scale=1.2).to(torch.bfloat16)
+    dctx = _rand(Mt, D, seed=9).to(torch.bfloat16)
+    seed, stream_id = 0xBEEF1234, 3 * 8 + 1
+    x = qkv.double().requires_grad_(True)
+    mask = None
+    if p:
+        mk = Masks(p, seed, B, Np, A)
+        mask = mk.attn(3, (B, A, N, N)).double()      # reference token order (CLS first), layer 3 -> stream 3 * 8 + 1
+    ctx_ref = torch.empty(Mt, D, dtype=torch.float64)
+    outs = []
+    for b in range(B):
+        r = torch.cat([torch.tensor([B * Np + b]), torch.arange(b * Np, (b + 1) * Np)])
+        q, k, v = [x[r][:, i * D:(i + 1) * D].reshape(N, A, 64).transpose(0, 1) for i in range(3)]
+        s = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+        if mask is not None:
+            s = s * mask[b]
+        o = (s @ v).transpose(0, 1).reshape(N, D)
+        ctx_ref[r] = o.detach()
+        outs.append((o * dctx.double()[r]).sum())
+    torch.stack(outs).sum().backward()
+    qd, dd = qkv.to(DEV), dctx.to(DEV)
+    ctx = torch.zeros(Mt, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B * A * N, device=DEV)
+    scr = torch.empty(B * A * N, device=DEV)
+    dqkv = torch.full((Mt, 3 * D), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().vitseg_op_attention_bwd_bf16(qd.data_ptr(), dd.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
+                                                       scr.data_ptr(), dqkv.data_ptr(), B, Np, A, p, seed, stream_id,
+                                                       _stream()))
+    got, ref = dqkv.float().cpu().double(), x.grad
+    assert torch.isfinite(got).all()
+    assert (ctx.float().cpu().double() - ctx_ref).abs().max().item() < 4e-2
+    # P, dS and the outputs are rounded to bf16 (2^-9): a few 1e-3 relative to the gradient scale, per slot
+    for i, name in enumerate(("dq", "dk", "dv")):
+        a, r_ = got[:, i * D:(i + 1) * D], ref[:, i * D:(i + 1) * D]
+        assert (a - r_).abs().max().item() < 2e-2 * r_.abs().max().item(), name
+        assert float((a - r_).norm() / r_.norm()) < 1e-2, name
+    # the CLS rows take the vector kernels: check them on their own
+    cls = slice(B * Np, Mt)
+    assert (got[cls] - ref[cls]).abs().max().item() < 2e-2 * ref[cls].abs().max().item()

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visiontransformer_amd import _lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("op", choices=["linear", "attention", "layernorm", "linear_ex", "wgrad"])
+ap.add_argument("op", choices=["linear", "attention", "layernorm", "linear_ex", "wgrad", "attn_bwd"])
 ap.add_argument("--M", type=int, default=32800)
 ap.add_argument("--N", type=int, default=3072)
 ap.add_argument("--K", type=int, default=768)
@@ -25,11 +25,24 @@ ap.add_argument("--Np", type=int, default=1024)
 ap.add_argument("--A", type=int, default=12)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--bf16", action="store_true")
+ap.add_argument("--drop", type=float, default=0.0)
 a = ap.parse_args()
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 L = _lib.lib()
-if a.op == "wgrad":   # dW[M,N] = dY^T X over K token rows, bf16 operands token-major
+if a.op == "attn_bwd":   # bf16 attention forward (with lse) + backward, optional attention dropout
+    D = 64 * a.A
+    Mt = a.B * a.Np + a.B
+    qkv = torch.randn(Mt, 3 * D, device=dev).to(torch.bfloat16)
+    dctx = torch.randn(Mt, D, device=dev).to(torch.bfloat16)
+    ctx = torch.empty(Mt, D, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(a.B * a.A * (a.Np + 1), device=dev)
+    scr = torch.empty_like(lse)
+    dqkv = torch.empty(Mt, 3 * D, device=dev, dtype=torch.bfloat16)
+    run = lambda: _lib.check(L.vitseg_op_attention_bwd_bf16(qkv.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
+                                                            scr.data_ptr(), dqkv.data_ptr(), a.B, a.Np, a.A, a.drop, 1234, 9, st))
+    work = 14.0 * a.B * a.A * (a.Np + 1) ** 2 * 64   # 2 + 5 products of 2 N^2 hd
+elif a.op == "wgrad":   # dW[M,N] = dY^T X over K token rows, bf16 operands token-major
     dY = torch.randn(a.K, a.M, device=dev).to(torch.bfloat16)
     X = torch.randn(a.K, a.N, device=dev).to(torch.bfloat16)
     dW = torch.empty(a.M, a.N, device=dev)

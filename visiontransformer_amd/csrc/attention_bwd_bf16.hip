@@ -1,12 +1,24 @@
-// Backward of the attention core, bf16 operands / fp32 accumulation (mixed-precision training).
-// Same algorithm and two-kernel, atomic-free structure as attention_bwd_f32.hip; the five products run on
-// v_mfma_f32_32x32x16_bf16:
-//   S / dP   : A = token rows from LDS (one ds_read_b128 per 16-wide k-step), B = this lane's row in registers;
-//   dQ^T = K^T dS^T,  dV^T = dO^T P,  dK^T = Q^T dS :
-//       B = the exponentiated / differentiated accumulator registers 8s..8s+7 packed to bf16 (the k index of a
-//       lane half is token 16s + 8(j>>2) + 4h + (j&3)); A = the TRANSPOSE of a row-major LDS tile, gathered with
-//       two ds_read_b64_tr_b16 per k-step (same addressing as V in attention_bf16.hip).
-// Inputs q|k|v, ctx, dctx are bf16; lse/delta fp32; dq|dk|dv are written as bf16.
+// Backward of the attention core, bf16 operands / fp32 accumulation (mixed-precision training): what autograd derives
+// for softmax(q k^T hd^-1/2) (dropout) v, transformers/models/vit/modeling_vit.py:164-189.  Flash-style: P is
+// recomputed from q, k and the forward's log-sum-exp; nothing of size N x N is stored.
+//
+//   S = c q k^T (log2 units, c = hd^-1/2 log2 e),  P = exp2(S - lse),  P~ = P o M (M = dropout keep / (1 - p)),
+//   dP~ = dO V^T,  dS = P o (dP~ o M - delta),  delta_i = sum_d dO_id O_id,
+//   dV = P~^T dO,   dK = hd^-1/2 dS^T Q,   dQ = hd^-1/2 dS K.
+//
+// Two MFMA kernels over the PATCH tokens (whole 64 / 128 token tiles at 512 x 512: no ragged tail, no per-element
+// bounds tests) plus the CLS token as rank-1 vector work, no atomics (bitwise reproducible):
+//   attn_bwd_dq : a block owns 128 patch queries (one per lane: S^T / dP^T tiles) and loops over the patch-key tiles;
+//                 dS^T registers are directly the B operand of dQ^T += K^T dS^T; the CLS key is one vector update.
+//   attn_bwd_dkv: a block owns 128 patch keys and loops over the patch-query tiles (a KEY on each lane; P / dS
+//                 registers are the B operands of dV^T += dO^T P~ and dK^T += Q^T dS); the CLS query is one vector update.
+//   attn_bwd_cls: dq of the CLS query and dk / dv of the CLS key (two reductions over all tokens) per (image, head).
+// The row constants enter as the INITIAL accumulators of the S and dP chains (-lse / c, -delta), so the inner element
+// work is  p = exp2(c s'),  ds = p dp'  -- no subtraction, no running maximum -- and the loop bodies are branch-free
+// (dropout and raggedness are template parameters): hipcc can then overlap one tile's MFMAs with the other's VALU.
+// A operands that are transposes of row-major LDS tiles are gathered with ds_read_b64_tr_b16 (as V in attention_bf16.hip).
+// Inputs q|k|v, ctx, dctx are bf16; lse / delta fp32; dq|dk|dv are written as bf16.  Roofline: MFMA bf16, 7 products
+// of 2 N^2 hd per (image, head) (S and dP are formed in both kernels).
 #include "kernels.hpp"
 
 namespace vitseg {
@@ -14,19 +26,15 @@ namespace {
 
 constexpr int HD = 64, TB = 128, TT = 64;
 constexpr float LOG2E = 1.4426950408889634f;
-typedef unsigned short bf16_t;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
-__device__ __forceinline__ size_t tok_row(int b, int n, int B, int Np) {
-    return n < Np ? (size_t)b * Np + n : (size_t)B * Np + b;
-}
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
 // delta[b][h][n] = sum_d dO * O.  A thread owns 8 consecutive channels of a token row (one 16-byte load of each
 // tensor), the 8 lanes of a head combine with three lane swaps; consecutive threads walk a row, so a wave reads 1 KiB
-// contiguous.  (One element per lane -- 128-byte loads -- ran at 1.1 TB/s.)
+// contiguous.
 __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const bf16_t* __restrict__ ctx,
                                                               const bf16_t* __restrict__ dctx,
                                                               float* __restrict__ delta, int B, int Np, int A) {
@@ -75,8 +83,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int t0, int dt, in
     return f;
 }
 
-// ---------------------------------------------------------------------------------- dQ
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
+// partial dot product of two 8 x 4 bf16-pair fragments (this lane's 32 of the 64 channels), completed across the lane halves
+__device__ __forceinline__ float dot_frag(const f32x4 (&a)[4], const f32x4 (&b)[4]) {
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned x = __float_as_uint(a[s][e]), y = __float_as_uint(b[s][e]);
+            part = fmaf(bf_lo(x), bf_lo(y), part);
+            part = fmaf(bf_hi(x), bf_hi(y), part);
+        }
+    return part + __shfl_xor(part, 32, 64);
+}
+
+// ---------------------------------------------------------------------------------- dQ (patch queries)
+template <bool DROP, bool RAGGED>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                   const bf16_t* __restrict__ dctx,
                                                                   const float* __restrict__ lse,
                                                                   const float* __restrict__ delta,
@@ -85,24 +108,26 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][TT * HD];  // [buffer][K|V]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const AttnTile at = attn_tile((Np + 1 + TB - 1) / TB, A);
+    const AttnTile at = attn_tile((Np + TB - 1) / TB, A);
     const int head = at.head, b = at.b;
     const int D = A * HD, ld = 3 * D, N = Np + 1;
+    const size_t row0 = (size_t)b * Np, cls_row = (size_t)B * Np + b;
     const bf16_t* kbase = qkv + D + head * HD;
     const bf16_t* vbase = qkv + 2 * D + head * HD;
     const float c = 0.125f * LOG2E;
 
     const int nq = at.rt * TB + wave * 32 + li;
-    const bool q_valid = nq < N;
-    const size_t q_row = tok_row(b, q_valid ? nq : 0, B, Np);
+    const bool q_valid = nq < Np;
+    const size_t q_row = row0 + (q_valid ? nq : Np - 1);
     f32x4 qf[4], dof[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         qf[s] = *(const f32x4*)(qkv + q_row * ld + head * HD + 16 * s + 8 * lh);
         dof[s] = *(const f32x4*)(dctx + q_row * (size_t)D + head * HD + 16 * s + 8 * lh);
     }
-    const size_t stat = ((size_t)b * A + head) * N + (q_valid ? nq : 0);
-    const float lse_q = lse[stat], delta_q = delta[stat];
+    const size_t stat = ((size_t)b * A + head) * N + (q_valid ? nq : Np - 1);
+    const float lse_q = lse[stat], ndelta = -delta[stat];
+    const float nlse = -lse_q * (1.0f / c);     // initial accumulator of the S chain: p = exp2(c (q.k - lse / c))
     const unsigned dkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + nq));  // same mask as forward
 
     f32x16 dq[2];
@@ -116,8 +141,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int key = min(kt * TT + lr + 32 * i, N - 1);
-            const size_t off = tok_row(b, key, B, Np) * ld + 8 * lc;
+            int key = kt * TT + lr + 32 * i;
+            if (RAGGED) key = min(key, Np - 1);   // duplicates are masked below
+            const size_t off = (row0 + key) * ld + 8 * lc;
             rk[i] = *(const f32x4*)(kbase + off);
             rv[i] = *(const f32x4*)(vbase + off);
         }
@@ -130,43 +156,55 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
             *(f32x4*)&lds[buf][1][tile_off(key, lc)] = rv[i];
         }
     };
-    const int nkt = (N + TT - 1) / TT;
+    const int nkt = (Np + TT - 1) / TT;
     gload(0);
     swrite(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         gload(min(kt + 1, nkt - 1));
-        __builtin_amdgcn_sched_barrier(0);
         const bf16_t* Ks = lds[buf][0];
         const bf16_t* Vs = lds[buf][1];
+        f32x16 st[2], dp[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16 st, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                st[kb][r] = nlse;
+                dp[kb][r] = DROP ? 0.f : ndelta;
+            }
             const int key = kb * 32 + li;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f32x4 kf = *(const f32x4*)&Ks[tile_off(key, 2 * s + lh)];
                 const f32x4 vf = *(const f32x4*)&Vs[tile_off(key, 2 * s + lh)];
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                             __builtin_bit_cast(bf16x8, qf[s]), st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                             __builtin_bit_cast(bf16x8, dof[s]), dp, 0, 0, 0);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                 __builtin_bit_cast(bf16x8, qf[s]), st[kb], 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                                 __builtin_bit_cast(bf16x8, dof[s]), dp[kb], 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
             unsigned pk[8];  // dS^T fragments: words 4 s + w = registers 8 s + 2 w, + 1
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float d0 = 0.f, d1 = 0.f;
-                const int k0 = kt * TT + kb * 32 + kappa(r, lh), k1 = kt * TT + kb * 32 + kappa(r + 1, lh);
-                float g0 = dp[r], g1 = dp[r + 1];
-                if (dr.thresh) {
-                    g0 = drop_keep(dkey, (unsigned)k0, dr.thresh) ? g0 * dr.scale : 0.f;
-                    g1 = drop_keep(dkey, (unsigned)k1, dr.thresh) ? g1 * dr.scale : 0.f;
+                const int k0 = kt * TT + kb * 32 + kappa(r, lh), k1 = k0 + 1;   // kappa(r + 1) = kappa(r) + 1 for even r
+                const float p0 = __builtin_amdgcn_exp2f(st[kb][r] * c), p1 = __builtin_amdgcn_exp2f(st[kb][r + 1] * c);
+                float d0, d1;
+                if (DROP) {
+                    const float m0 = drop_keep(dkey, (unsigned)k0, dr.thresh) ? dr.scale : 0.f;
+                    const float m1 = drop_keep(dkey, (unsigned)k1, dr.thresh) ? dr.scale : 0.f;
+                    d0 = p0 * fmaf(dp[kb][r], m0, ndelta);
+                    d1 = p1 * fmaf(dp[kb][r + 1], m1, ndelta);
+                } else {
+                    d0 = p0 * dp[kb][r];
+                    d1 = p1 * dp[kb][r + 1];
                 }
-                if (k0 < N) d0 = __builtin_amdgcn_exp2f(fmaf(st[r], c, -lse_q)) * (g0 - delta_q);
-                if (k1 < N) d1 = __builtin_amdgcn_exp2f(fmaf(st[r + 1], c, -lse_q)) * (g1 - delta_q);
+                if (RAGGED) {
+                    d0 = k0 < Np ? d0 : 0.f;
+                    d1 = k1 < Np ? d1 : 0.f;
+                }
                 pk[r >> 1] = pack2_bf16(d0, d1);
             }
 #pragma unroll
@@ -180,6 +218,30 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
         }
         swrite(buf ^ 1);
         __syncthreads();
+    }
+    // ---- the CLS key: one vector update per query (ds is a scalar per lane) ----
+    {
+        f32x4 kc[4], vc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kc[s] = *(const f32x4*)(kbase + cls_row * ld + 16 * s + 8 * lh);
+            vc[s] = *(const f32x4*)(vbase + cls_row * ld + 16 * s + 8 * lh);
+        }
+        const float sc = dot_frag(qf, kc), dpc = dot_frag(dof, vc);
+        const float p = __builtin_amdgcn_exp2f(fmaf(sc, c, -lse_q));
+        float m = 1.f;
+        if (DROP) m = drop_keep(dkey, (unsigned)Np, dr.thresh) ? dr.scale : 0.f;
+        const float ds = p * fmaf(dpc, m, ndelta);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {   // accumulator register 4 g4 + e = channel 32 dt + 8 g4 + 4 lh + e
+                const uint2 t = *(const uint2*)(kbase + cls_row * ld + dt * 32 + 8 * g4 + 4 * lh);
+                dq[dt][4 * g4 + 0] = fmaf(ds, bf_lo(t.x), dq[dt][4 * g4 + 0]);
+                dq[dt][4 * g4 + 1] = fmaf(ds, bf_hi(t.x), dq[dt][4 * g4 + 1]);
+                dq[dt][4 * g4 + 2] = fmaf(ds, bf_lo(t.y), dq[dt][4 * g4 + 2]);
+                dq[dt][4 * g4 + 3] = fmaf(ds, bf_hi(t.y), dq[dt][4 * g4 + 3]);
+            }
     }
     if (q_valid) {
         bf16_t* out = dqkv + q_row * ld + head * HD;
@@ -195,7 +257,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
     }
 }
 
-// ---------------------------------------------------------------------------------- dK, dV
+// ---------------------------------------------------------------------------------- dK, dV (patch keys)
+template <bool DROP, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                    const bf16_t* __restrict__ dctx,
                                                                    const float* __restrict__ lse,
@@ -203,17 +266,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                                                                    bf16_t* __restrict__ dqkv, int B, int Np, int A,
                                                                    DropArgs dr) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][TT * HD];  // [buffer][Q|dO]
-    __shared__ float stats[2][3][TT];
+    __shared__ __attribute__((aligned(16))) float stats[2][3][TT];      // -lse / c, -delta, dropout key of the tile's queries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const AttnTile at = attn_tile((Np + 1 + TB - 1) / TB, A);
+    const AttnTile at = attn_tile((Np + TB - 1) / TB, A);
     const int head = at.head, b = at.b;
     const int D = A * HD, ld = 3 * D, N = Np + 1;
-    const float c = 0.125f * LOG2E;
+    const size_t row0 = (size_t)b * Np, cls_row = (size_t)B * Np + b;
+    const size_t stat0 = ((size_t)b * A + head) * N;
+    const float c = 0.125f * LOG2E, inv_c = 1.0f / c;
 
     const int nk = at.rt * TB + wave * 32 + li;
-    const bool k_valid = nk < N;
-    const size_t k_row = tok_row(b, k_valid ? nk : 0, B, Np);
+    const bool k_valid = nk < Np;
+    const size_t k_row = row0 + (k_valid ? nk : Np - 1);
     f32x4 kf[4], vf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -233,17 +298,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
     auto gload = [&](int qt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int q = min(qt * TT + lr + 32 * i, N - 1);
-            const size_t row = tok_row(b, q, B, Np);
+            int q = qt * TT + lr + 32 * i;
+            if (RAGGED) q = min(q, Np - 1);
+            const size_t row = row0 + q;
             rq[i] = *(const f32x4*)(qkv + row * ld + head * HD + 8 * lc);
             rd[i] = *(const f32x4*)(dctx + row * (size_t)D + head * HD + 8 * lc);
         }
         if (tid < TT) {
-            const int q = min(qt * TT + tid, N - 1);
-            rs = lse[((size_t)b * A + head) * N + q];
-            rdl = delta[((size_t)b * A + head) * N + q];
+            const int q = qt * TT + tid;
+            const bool ok = !RAGGED || q < Np;
+            const size_t si = stat0 + (ok ? q : Np - 1);
+            // a query beyond the last patch gets p = exp2(c * -inf) = 0 and contributes nothing
+            rs = ok ? -lse[si] * inv_c : -INFINITY;
+            rdl = ok ? -delta[si] : 0.f;
             // the query's dropout key, hashed ONCE per query here instead of once per (query, key) element below
-            rkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + qt * TT + tid));
+            if (DROP) rkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + q));
         }
     };
     auto swrite = [&](int buf) {
@@ -259,21 +328,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
             stats[buf][2][tid] = __uint_as_float(rkey);
         }
     };
-    const int nqt = (N + TT - 1) / TT;
+    const int nqt = (Np + TT - 1) / TT;
     gload(0);
     swrite(0);
     __syncthreads();
     for (int qt = 0; qt < nqt; ++qt) {
         const int buf = qt & 1;
         gload(min(qt + 1, nqt - 1));
-        __builtin_amdgcn_sched_barrier(0);
         const bf16_t* Qs = lds[buf][0];
         const bf16_t* Os = lds[buf][1];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            f32x16 st, dp;
+            // accumulator register 4 g4 + e <-> query qb * 32 + 8 g4 + 4 lh + e: four consecutive row constants per 16-byte read
+            f32x16 st, dp, dl;
+            unsigned rk16[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int q0 = qb * 32 + 8 * g4 + 4 * lh;
+                const f32x4 a = *(const f32x4*)&stats[buf][0][q0];
+                const f32x4 d4 = *(const f32x4*)&stats[buf][1][q0];
+                f32x4 k4 = {0.f, 0.f, 0.f, 0.f};
+                if (DROP) k4 = *(const f32x4*)&stats[buf][2][q0];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[4 * g4 + e] = a[e];
+                    dp[4 * g4 + e] = DROP ? 0.f : d4[e];
+                    dl[4 * g4 + e] = d4[e];
+                    rk16[4 * g4 + e] = __float_as_uint(k4[e]);
+                }
+            }
             const int q = qb * 32 + li;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -284,20 +367,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, oa),
                                                              __builtin_bit_cast(bf16x8, vf[s]), dp, 0, 0, 0);
             }
-            unsigned pp[8], pd[8];  // P and dS fragments (B operands), query = register index
+            unsigned pp[8], pd[8];  // P~ and dS fragments (B operands), query = register index
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float p0 = 0.f, p1 = 0.f;
-                const int q0 = qb * 32 + kappa(r, lh), q1 = qb * 32 + kappa(r + 1, lh);
-                if (qt * TT + q0 < N) p0 = __builtin_amdgcn_exp2f(fmaf(st[r], c, -stats[buf][0][q0]));
-                if (qt * TT + q1 < N) p1 = __builtin_amdgcn_exp2f(fmaf(st[r + 1], c, -stats[buf][0][q1]));
-                float k0 = 1.f, k1 = 1.f;
-                if (dr.thresh) {
-                    k0 = drop_keep(__float_as_uint(stats[buf][2][q0]), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
-                    k1 = drop_keep(__float_as_uint(stats[buf][2][q1]), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                const float p0 = __builtin_amdgcn_exp2f(st[r] * c), p1 = __builtin_amdgcn_exp2f(st[r + 1] * c);
+                if (DROP) {
+                    const float m0 = drop_keep(rk16[r], (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                    const float m1 = drop_keep(rk16[r + 1], (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                    pp[r >> 1] = pack2_bf16(p0 * m0, p1 * m1);  // dropped P (what multiplied V in the forward)
+                    pd[r >> 1] = pack2_bf16(p0 * fmaf(dp[r], m0, dl[r]), p1 * fmaf(dp[r + 1], m1, dl[r + 1]));
+                } else {
+                    pp[r >> 1] = pack2_bf16(p0, p1);
+                    pd[r >> 1] = pack2_bf16(p0 * dp[r], p1 * dp[r + 1]);
                 }
-                pp[r >> 1] = pack2_bf16(p0 * k0, p1 * k1);  // dropped P (what multiplied V in the forward)
-                pd[r >> 1] = pack2_bf16(p0 * (dp[r] * k0 - stats[buf][1][q0]), p1 * (dp[r + 1] * k1 - stats[buf][1][q1]));
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -314,6 +396,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
         }
         swrite(buf ^ 1);
         __syncthreads();
+    }
+    // ---- the CLS query: one vector update per key (p and ds are scalars per lane) ----
+    {
+        f32x4 qc[4], oc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qc[s] = *(const f32x4*)(qkv + cls_row * ld + head * HD + 16 * s + 8 * lh);
+            oc[s] = *(const f32x4*)(dctx + cls_row * (size_t)D + head * HD + 16 * s + 8 * lh);
+        }
+        const float sc = dot_frag(kf, qc), dpc = dot_frag(vf, oc);
+        const float p = __builtin_amdgcn_exp2f(fmaf(sc, c, -lse[stat0 + Np]));
+        float m = 1.f;
+        if (DROP) m = drop_keep(drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + Np)), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+        const float pm = p * m, ds = p * fmaf(dpc, m, -delta[stat0 + Np]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const uint2 tq = *(const uint2*)(qkv + cls_row * ld + head * HD + dt * 32 + 8 * g4 + 4 * lh);
+                const uint2 to = *(const uint2*)(dctx + cls_row * (size_t)D + head * HD + dt * 32 + 8 * g4 + 4 * lh);
+                dk[dt][4 * g4 + 0] = fmaf(ds, bf_lo(tq.x), dk[dt][4 * g4 + 0]);
+                dk[dt][4 * g4 + 1] = fmaf(ds, bf_hi(tq.x), dk[dt][4 * g4 + 1]);
+                dk[dt][4 * g4 + 2] = fmaf(ds, bf_lo(tq.y), dk[dt][4 * g4 + 2]);
+                dk[dt][4 * g4 + 3] = fmaf(ds, bf_hi(tq.y), dk[dt][4 * g4 + 3]);
+                dv[dt][4 * g4 + 0] = fmaf(pm, bf_lo(to.x), dv[dt][4 * g4 + 0]);
+                dv[dt][4 * g4 + 1] = fmaf(pm, bf_hi(to.x), dv[dt][4 * g4 + 1]);
+                dv[dt][4 * g4 + 2] = fmaf(pm, bf_lo(to.y), dv[dt][4 * g4 + 2]);
+                dv[dt][4 * g4 + 3] = fmaf(pm, bf_hi(to.y), dv[dt][4 * g4 + 3]);
+            }
     }
     if (k_valid) {
         bf16_t* outk = dqkv + k_row * ld + D + head * HD;
@@ -333,23 +444,123 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
     }
 }
 
+// ---------------------------------------------------------------------------------- the CLS token
+// dq of the CLS query (sum over all N keys) and dk, dv of the CLS key (sums over all N queries) of one (head, image):
+// 8 lanes share a token row (16 bytes each: whole 128-byte lines), 32 tokens per pass, fp32 vector arithmetic.
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_cls_bf16_kernel(const bf16_t* __restrict__ qkv,
+                                                                const bf16_t* __restrict__ dctx,
+                                                                const float* __restrict__ lse,
+                                                                const float* __restrict__ delta,
+                                                                bf16_t* __restrict__ dqkv, int B, int Np, int A,
+                                                                DropArgs dr) {
+    __shared__ float red[3][32][HD];
+    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int D = A * HD, ld = 3 * D, N = Np + 1;
+    const size_t row0 = (size_t)b * Np, cls_row = (size_t)B * Np + b;
+    const size_t stat0 = ((size_t)b * A + head) * N;
+    const float c = 0.125f * LOG2E;
+    auto load8 = [&](const bf16_t* ptr, float (&out)[8]) {
+        const uint4 u = *(const uint4*)ptr;
+        out[0] = bf_lo(u.x); out[1] = bf_hi(u.x); out[2] = bf_lo(u.y); out[3] = bf_hi(u.y);
+        out[4] = bf_lo(u.z); out[5] = bf_hi(u.z); out[6] = bf_lo(u.w); out[7] = bf_hi(u.w);
+    };
+    auto dot8 = [&](const float (&x)[8], const float (&y)[8]) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(x[e], y[e], s);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        return s;
+    };
+    float qc[8], kc[8], vc[8], oc[8];
+    load8(qkv + cls_row * ld + head * HD + 8 * sub, qc);
+    load8(qkv + cls_row * ld + D + head * HD + 8 * sub, kc);
+    load8(qkv + cls_row * ld + 2 * D + head * HD + 8 * sub, vc);
+    load8(dctx + cls_row * (size_t)D + head * HD + 8 * sub, oc);
+    const float lse_c = lse[stat0 + Np], delta_c = delta[stat0 + Np];
+    const unsigned key_c = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + Np));
+    float aq[8], ak[8], av[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aq[e] = ak[e] = av[e] = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 32) {
+        const int n = n0 + grp;
+        const bool ok = n < N;
+        const size_t row = !ok ? cls_row : (n < Np ? row0 + n : cls_row);
+        float qn[8], kn[8], vn[8], on[8];
+        load8(qkv + row * ld + head * HD + 8 * sub, qn);
+        load8(qkv + row * ld + D + head * HD + 8 * sub, kn);
+        load8(qkv + row * ld + 2 * D + head * HD + 8 * sub, vn);
+        load8(dctx + row * (size_t)D + head * HD + 8 * sub, on);
+        // token n as a KEY of the CLS query
+        const float s1 = dot8(qc, kn), d1 = dot8(oc, vn);
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s1, c, -lse_c));
+        float m1 = 1.f;
+        if (DROP) m1 = drop_keep(key_c, (unsigned)n, dr.thresh) ? dr.scale : 0.f;
+        const float ds1 = ok ? p1 * fmaf(d1, m1, -delta_c) : 0.f;
+        // token n as a QUERY of the CLS key
+        const size_t sn = stat0 + (ok ? n : Np);
+        const float s2 = dot8(qn, kc), d2 = dot8(on, vc);
+        const float p2 = __builtin_amdgcn_exp2f(fmaf(s2, c, -lse[sn]));
+        float m2 = 1.f;
+        if (DROP) m2 = drop_keep(drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + n)), (unsigned)Np, dr.thresh) ? dr.scale : 0.f;
+        const float pm2 = ok ? p2 * m2 : 0.f;
+        const float ds2 = ok ? p2 * fmaf(d2, m2, -delta[sn]) : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            aq[e] = fmaf(ds1, kn[e], aq[e]);
+            ak[e] = fmaf(ds2, qn[e], ak[e]);
+            av[e] = fmaf(pm2, on[e], av[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[0][grp][8 * sub + e] = aq[e];
+        red[1][grp][8 * sub + e] = ak[e];
+        red[2][grp][8 * sub + e] = av[e];
+    }
+    __syncthreads();
+    if (tid < 3 * HD) {
+        const int which = tid / HD, d = tid - which * HD;
+        float s = 0.f;
+        for (int g = 0; g < 32; ++g) s += red[which][g][d];   // fixed order: deterministic
+        if (which < 2) s *= 0.125f;
+        dqkv[cls_row * ld + which * D + head * HD + d] = f32_to_bf16(s);
+    }
+}
+
+template <bool DROP>
+int launch_bwd(const bf16_t* qkv, const bf16_t* dctx, const float* lse, const float* dvec, bf16_t* dqkv, int B, int Np,
+               int A, DropArgs dr, hipStream_t s) {
+    const dim3 grid((unsigned)((Np + TB - 1) / TB) * A * B);  // 1-D: attn_tile() places the tiles
+    if (Np % TB == 0) {
+        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DROP, false>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
+        VITSEG_LAUNCH_CHECK("attn_bwd_dq_bf16");
+        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DROP, false>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
+        VITSEG_LAUNCH_CHECK("attn_bwd_dkv_bf16");
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DROP, true>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
+        VITSEG_LAUNCH_CHECK("attn_bwd_dq_bf16");
+        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DROP, true>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
+        VITSEG_LAUNCH_CHECK("attn_bwd_dkv_bf16");
+    }
+    hipLaunchKernelGGL(attn_bwd_cls_bf16_kernel<DROP>, dim3(A, B), dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
+    VITSEG_LAUNCH_CHECK("attn_bwd_cls_bf16");
+    return VITSEG_OK;
+}
+
 }  // namespace
 
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dvec,
                               void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && dctx && lse && dvec && dqkv, VITSEG_EINVAL, "attention_bwd_bf16: null pointer");
-    const int N = Np + 1;
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3((unsigned)(((size_t)B * (Np + 1) * A * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ctx,
                        (const bf16_t*)dctx, dvec, B, Np, A);
     VITSEG_LAUNCH_CHECK("attn_delta_bf16");
-    const dim3 grid((unsigned)((N + TB - 1) / TB) * A * B);  // 1-D: attn_tile() places the tiles
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec,
-                       (bf16_t*)dqkv, B, Np, A, dr);
-    VITSEG_LAUNCH_CHECK("attn_bwd_dq_bf16");
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec,
-                       (bf16_t*)dqkv, B, Np, A, dr);
-    VITSEG_LAUNCH_CHECK("attn_bwd_dkv_bf16");
-    return VITSEG_OK;
+    return dr.thresh ? launch_bwd<true>((const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s)
+                     : launch_bwd<false>((const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s);
 }
 
 }  // namespace vitseg

@@ -451,6 +451,25 @@ int vitseg_op_attention_bwd_f32(const float* qkv, const float* dctx, float* ctx_
                                     (hipStream_t)stream);
 }
 
+// bf16 forward (saving the log-sum-exp, optional attention-probability dropout) + backward of the attention core
+int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_out, float* lse_out, float* scratch,
+                                 void* dqkv, int batch, int num_patches, int num_heads, float dropout_p,
+                                 uint32_t dropout_seed, uint32_t dropout_stream, void* stream) {
+    VITSEG_CHECK_ARG(qkv && dctx && ctx_out && lse_out && scratch && dqkv, VITSEG_EINVAL, "attention_bwd: null pointer");
+    VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "attention_bwd: dropout_p %f", dropout_p);
+    DropArgs d{};
+    if (dropout_p > 0.f) {
+        d.thresh = (unsigned)((double)dropout_p * 65536.0 + 0.5);
+        if (d.thresh == 0) d.thresh = 1;
+        d.seed = dropout_seed;
+        d.stream = dropout_stream;
+        d.scale = 1.0f / (1.0f - dropout_p);
+    }
+    if (int rc = launch_attention_bf16(qkv, ctx_out, lse_out, batch, num_patches, num_heads, d, (hipStream_t)stream)) return rc;
+    return launch_attention_bwd_bf16(qkv, ctx_out, dctx, lse_out, scratch, dqkv, batch, num_patches, num_heads, d,
+                                     (hipStream_t)stream);
+}
+
 int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out,
                                 float* dw, float* db, float* scratch, int rows, int D, float eps, void* stream) {
     return launch_layernorm_bwd(x, w, g, 0, dres_in, dres_out, dw, db, scratch, rows, D, eps, (hipStream_t)stream);
