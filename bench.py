@@ -301,7 +301,7 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = model.ce_loss(x, y)
+        loss = model.ce_loss(x, y, grad_scale=1.0)   # the factor is folded into the CE gradient: no arena-sized multiply
         loss.backward()
         sync_grads(model)
         opt.step(grad_scale=1.0 / world)

@@ -194,15 +194,17 @@ int vitseg_ce_loss(const float* lowres, const void* target, int target_is_u8, fl
  * (vitseg_train_workspace bytes; it must stay untouched until vitseg_backward has run) and optionally
  * writes the fp32 logits.  vitseg_backward takes EITHER integer targets (fused CE: writes the mean loss to
  * *loss) OR the gradient of an arbitrary loss w.r.t. the logits (fp32 [B, C, S, S]) and fills `grads`, an
- * arena-shaped fp32 buffer (same offsets as the parameters). */
+ * arena-shaped fp32 buffer (same offsets as the parameters).  loss_scale multiplies the gradient of the fused CE loss
+ * at its source (1 / accumulate_grad_batches in a gradient-accumulation loop, what Lightning applies to every micro-batch
+ * loss); the value written to *loss is not scaled. */
 int vitseg_train_workspace(const vitseg_config* cfg, int batch, int precision, size_t* bytes);
 int vitseg_forward_train(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x,
                          int batch, int precision, float dropout_p, uint64_t dropout_seed, float* logits,
                          void* workspace, size_t workspace_bytes, void* stream);
 int vitseg_backward(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x, int batch,
                     int precision, float dropout_p, uint64_t dropout_seed, const void* target, int target_is_u8,
-                    const float* grad_logits, float* grads, float* loss, void* const* bucket_events, void* workspace,
-                    size_t workspace_bytes, void* stream);
+                    const float* grad_logits, float* grads, float* loss, float loss_scale, void* const* bucket_events,
+                    void* workspace, size_t workspace_bytes, void* stream);
 /* Gradient buckets for overlapping the data-parallel all-reduce with the backward (the reference
  * trains single-process, this replaces what DDP would do behind trainer.fit, trainCurrentViTmodel.py:97-101).
  * The gradient arena splits into vitseg_grad_bucket_count() = L + 2 contiguous ranges in the order the backward
@@ -242,6 +244,17 @@ int vitseg_resize_nearest_u8(const uint8_t* src, int n, int H, int W, const int3
 size_t vitseg_paed_scratch_bytes(int batch, int C, int H, int W);
 int vitseg_paed_multiclass_loss(const float* logits, const void* target, int target_is_u8, int batch, int C, int H, int W,
                                 float sigma, int class_penalty, void* scratch, float* loss, float* grad_logits, void* stream);
+
+/* ---- loss tail of the binary PAED trainer (replaces sigmoid + F.binary_cross_entropy + dice_loss + paed_loss_soft
+ *      and their autograd in PAEDTrainer._forward_step_paed, model/PAED/classes.py:608-701).  logits fp32 [B, 1, H, W];
+ *      mask fp32 0/1 [B, H, W] (already resized to the prediction); sdf_ext / sdf_int fp32 [B, sdf_h, sdf_w] (resized
+ *      bilinearly on the fly).  out8 (device, 8 floats): loss = bce + 0.1 dice + 5 |paed|, bce, dice, paed, then the
+ *      counts tp, fp, fn and #((p > 0.5) == mask) for the trainer's logged metrics.  grad_logits (optional) receives
+ *      d loss / d logits.  scratch: vitseg_paed_binary_scratch_bytes() device bytes. */
+size_t vitseg_paed_binary_scratch_bytes(int batch, int H, int W);
+int vitseg_paed_binary_loss(const float* logits, const float* mask, const float* sdf_ext, const float* sdf_int, int sdf_h,
+                            int sdf_w, int batch, int H, int W, void* scratch, float* out8, float* grad_logits,
+                            void* stream);
 
 /* ---- evaluation statistics (replaces the per-image numpy loops of datasetTestViTmodel.py:193-219) ----
  * pred: uint8 [n, S, S] class masks; gt: uint8 [n, gt_h, gt_w] label maps, nearest-resized on the fly through

@@ -15,6 +15,12 @@ def fmix32(h):
     return h
 
 
+def mad24(a, k, c):
+    """low 24 bits of a times the 24-bit constant k, plus c, mod 2^32 (v_mad_u32_u24)"""
+    a, c = np.broadcast_arrays(np.asarray(a, dtype=np.uint32), np.asarray(c, dtype=np.uint32))
+    return ((a.astype(np.uint64) & np.uint64(0xFFFFFF)) * np.uint64(k & 0xFFFFFF) + c.astype(np.uint64)).astype(np.uint32)
+
+
 class Masks:
     def __init__(self, p, seed64, B, Np, A):
         self.p, self.B, self.Np, self.A = p, B, Np, A
@@ -26,7 +32,10 @@ class Masks:
         with np.errstate(over="ignore"):
             key = fmix32(self.seed ^ (np.uint32(stream) * np.uint32(0x9E3779B1)) ^ (major.astype(np.uint32) * np.uint32(0x85EBCA77)))
             m = minor.astype(np.uint32)
-            h = fmix32((m >> np.uint32(1)) ^ key)
+            h = mad24(m >> np.uint32(1), 0x9E3779, key)
+            h ^= h >> np.uint32(15)
+            h = mad24(h, 0x85EBCB, h >> np.uint32(9))
+            h ^= h >> np.uint32(14)
             return np.where(m & np.uint32(1), h >> np.uint32(16), h & np.uint32(0xFFFF)) >= self.thresh
 
     def _gen(self, n_ref):  # reference token index (CLS first) -> generic index (CLS last)

@@ -162,3 +162,101 @@ def test_bucket_reducer_gloo_world2():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert ok and ngroups > 1
+
+
+# ---------------------------------------------------------------- gradient accumulation under data parallelism
+class _StubNet(torch.nn.Module):
+    """Stands in for ViTSegmentationModel on the CPU: one flat `arena` parameter, the `no_sync()` / `_overlap_active()`
+    protocol of visiontransformer_amd/model.py (the real methods are borrowed, not re-implemented)."""
+    from visiontransformer_amd.model import ViTSegmentationModel as _M
+    no_sync = _M.no_sync
+    _overlap_active = _M._overlap_active
+
+    def __init__(self):
+        super().__init__()
+        self.arena = torch.nn.Parameter(torch.linspace(-1, 1, 64))
+        self.grad_sync, self._grads_reduced, self._require_sync = "overlap", False, True
+
+
+class _StubLightning(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.model = _StubNet()
+        self.overlap_seen = []
+
+    def training_step(self, batch, idx):
+        x, y = batch
+        self.overlap_seen.append(self.model._overlap_active())   # what the real backward would consult
+        return ((self.model.arena * x).sum(dim=1) - y).pow(2).mean()
+
+    def validation_step(self, batch, idx):
+        return self.training_step(batch, idx).detach()
+
+    def configure_optimizers(self):
+        return torch.optim.SGD(self.parameters(), lr=0.1)
+
+    def state_dict(self, *a, **k):
+        return {"model.arena": self.model.arena.detach().clone()}
+
+    def load_state_dict(self, sd, strict=True, assign=False):
+        with torch.no_grad():
+            self.model.arena.copy_(sd["model.arena"])
+
+
+def _accum_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from visiontransformer_amd import trainer
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(t.numel())
+        return real(t, *a, **k)
+
+    dist.all_reduce = counting
+    g = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(16, 2, 64, generator=g), torch.randn(16, 2, generator=g)     # 16 micro-batches of 2 samples
+    mine = [(X[i], Y[i]) for i in range(rank, 16, world)]                           # 8 per rank
+    lm = _StubLightning()
+    w0 = lm.model.arena.detach().clone()
+    trainer.fit(lm, mine, None, max_epochs=1, accumulate_grad_batches=4, device="cpu")
+    grad_calls = [n for n in calls if n == 64]
+    # reference: one process, the same 16 micro-batches, 2 optimizer steps of 8 micro-batches each (4 per rank x 2 ranks)
+    ref = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.SGD([ref], lr=0.1)
+    for s in range(2):
+        opt.zero_grad()
+        for r in range(world):
+            for j in range(4):
+                i = r + world * (4 * s + j)
+                (((ref * X[i]).sum(dim=1) - Y[i]).pow(2).mean() / 4 / world).backward()
+        opt.step()
+    if rank == 0:
+        q.put((len(grad_calls), bool(torch.allclose(lm.model.arena.detach(), ref.detach(), atol=1e-6)),
+               lm.overlap_seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_reduces_once_per_optimizer_step_gloo_world2():
+    """trainer.fit with accumulate_grad_batches=4 on 2 ranks: 8 micro-batches per rank = 2 optimizer steps -> exactly 2
+    gradient all-reduces (not 8), micro-batches 1-3 of a step run under no_sync(), and the parameters equal the
+    single-process run over the same 16 micro-batches."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n_calls, same, overlap_seen = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert n_calls == 2 and same
+    # the overlapped (in-backward) reduce is never taken while an accumulated gradient is pending or inside no_sync():
+    # only a step's first micro-batch could use it, and that one runs under no_sync() when it is not also the last
+    assert overlap_seen == [False] * 8

@@ -213,3 +213,50 @@ def test_paed_multiclass_fused_matches_torch_autograd(B, C, H, W, sigma, pen, u8
     with torch.no_grad():                        # no gradient requested: loss only
         assert abs(paed.paed_multiclass_loss_fused(logits.to(DEV), yt, sigma=sigma, class_penalty=pen).item() - ref.item()) \
             < 3e-6 * max(1.0, abs(ref.item()))
+
+
+# ---------------------------------------------------------------- row f1, second half: the binary PAED trainer's loss tail
+def test_paed_binary_fused_matches_reference_golden():
+    """csrc/paed_binary.hip (sigmoid + BCE + 0.1 Dice + 5 |soft PAED|, value and gradient) against the outputs of the REAL
+    reference methods dice_loss / paed_loss_soft + F.binary_cross_entropy (model/PAED/classes.py:608-681; fixture from
+    oracle/make_golden_paed.py)."""
+    from oracle.make_golden_paed import paed_inputs
+    from visiontransformer_amd import paed
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "paed", "paed_losses.npz"))
+    _, _, blogits, bmask, sdf_ext, sdf_int = paed_inputs()
+    lg = blogits.to(DEV).requires_grad_(True)
+    loss, terms = paed.paed_binary_loss_fused(lg, bmask.to(DEV), sdf_ext[:, 0].to(DEV), sdf_int[:, 0].to(DEV))
+    loss.backward()
+    t = terms.cpu().numpy()
+    assert abs(t[3] - float(G["binary.paed"][0])) < 2e-6 and abs(t[2] - float(G["binary.dice"][0])) < 2e-6
+    assert abs(loss.item() - float(G["binary.total"][0])) < 2e-6 * max(1.0, abs(float(G["binary.total"][0])))
+    ref = G["binary.grad"]
+    assert np.abs(lg.grad.cpu().numpy() - ref).max() < 5e-6 * np.abs(ref).max() + 1e-12
+    p = torch.sigmoid(blogits)
+    b = (p > 0.5).float()
+    assert t[4] == float((b * bmask).sum()) and t[5] == float((b * (1 - bmask)).sum())
+    assert t[6] == float(((1 - b) * bmask).sum()) and t[7] == float((b == bmask).sum())
+
+
+@pytest.mark.parametrize("B,H,W,hs,ws", [(2, 224, 224, 64, 64), (1, 50, 70, 20, 31), (3, 33, 21, 33, 21), (1, 96, 96, 128, 128)])
+def test_paed_binary_fused_matches_torch_autograd(B, H, W, hs, ws):
+    """Shapes the fixture does not hold (non-square, tiles with ragged edges, SDFs larger than the prediction) against fp64
+    autograd through the plain-torch restatement of the reference methods (visiontransformer_amd/paed.py)."""
+    import torch.nn.functional as F
+    from visiontransformer_amd import paed
+    g = torch.Generator().manual_seed(B * 100 + H)
+    z = torch.randn(B, 1, H, W, generator=g) * 2
+    m = (torch.rand(B, 1, H, W, generator=g) > 0.55).float()
+    se, si = torch.rand(B, hs, ws, generator=g) * 5, torch.rand(B, hs, ws, generator=g) * 3
+    zd = z.double().requires_grad_(True)
+    pr = torch.sigmoid(zd)
+    pa = paed.paed_loss_soft(se.unsqueeze(1).double(), si.unsqueeze(1).double(), pr)
+    ref = F.binary_cross_entropy(pr, m.double()) + 0.1 * paed.dice_loss(pr, m.double()).double() + 5.0 * pa.abs()
+    ref.backward()
+    lg = z.to(DEV).requires_grad_(True)
+    loss, terms = paed.paed_binary_loss_fused(lg, m.to(DEV), se.to(DEV), si.to(DEV))
+    (loss * 2.0).backward()
+    assert abs(loss.item() - ref.item()) < 5e-6 * max(1.0, abs(ref.item()))
+    assert abs(float(terms[3]) - pa.item()) < 5e-6
+    gr = zd.grad.numpy() * 2.0
+    assert np.abs(lg.grad.cpu().numpy() - gr).max() < 2e-5 * np.abs(gr).max() + 1e-12

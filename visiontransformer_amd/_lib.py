@@ -34,6 +34,7 @@ EXPORTS = [
     "vitseg_resize_nearest_u8", "vitseg_eval_counts", "vitseg_paed_scratch_bytes", "vitseg_paed_multiclass_loss",
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32", "vitseg_op_linear_h16_ex",
     "vitseg_op_wgrad_bf16", "vitseg_op_wgrad_bf16_scratch_floats", "vitseg_op_attention_bwd_bf16",
+    "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
                 "head1x1", "upsample"]
@@ -95,12 +96,15 @@ def lib() -> C.CDLL:
         f32 = C.c_float
         l.vitseg_train_workspace.argtypes = [pcfg, i32, i32, psz]
         l.vitseg_forward_train.argtypes = [pcfg, vp, vp, vp, i32, i32, f32, C.c_uint64, vp, vp, sz, vp]
-        l.vitseg_backward.argtypes = [pcfg, vp, vp, vp, i32, i32, f32, C.c_uint64, vp, i32, vp, vp, vp, vp, vp, sz, vp]
+        l.vitseg_backward.argtypes = [pcfg, vp, vp, vp, i32, i32, f32, C.c_uint64, vp, i32, vp, vp, vp, f32, vp, vp, sz, vp]
         l.vitseg_grad_bucket_count.argtypes = [pcfg]
         l.vitseg_resize_taps.argtypes = [i32, i32]
         l.vitseg_paed_scratch_bytes.argtypes = [i32, i32, i32, i32]
         l.vitseg_paed_scratch_bytes.restype = sz
         l.vitseg_paed_multiclass_loss.argtypes = [vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp]
+        l.vitseg_paed_binary_scratch_bytes.argtypes = [i32, i32, i32]
+        l.vitseg_paed_binary_scratch_bytes.restype = sz
+        l.vitseg_paed_binary_loss.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
         l.vitseg_resize_coeffs.argtypes = [i32, i32, vp, vp]
         l.vitseg_nearest_index.argtypes = [i32, i32, i32, vp]
         l.vitseg_preprocess_u8.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]

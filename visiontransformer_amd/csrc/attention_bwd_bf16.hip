@@ -65,9 +65,15 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const bf16_t* __re
     }
 }
 
-// One [64 tokens][64 d] bf16 tile: rows of 128 B, 16-byte chunk c of row r stored at c ^ ((r >> 1) & 7)
-// (conflict-free ds_read_b128 row reads; the transposed reads below go through the same map).
-__device__ __forceinline__ int tile_off(int row, int chunk) { return row * HD + ((chunk ^ ((row >> 1) & 7)) << 3); }
+// One [64 tokens][64 d] bf16 tile serves BOTH kinds of read: rows of 128 B, 16-byte chunk c of row r stored at
+// c ^ f(r), f = the 3 bits of r >> 1 rotated right by one.  f is a bijection of (r >> 1) & 7, so the 16 rows of a
+// ds_read_b128 lane group still hit 16 distinct 16-byte slots; and rows r, r + 2 of a transposed read (4 rows x 64 B
+// per half-wave) now differ in bit 2 of f, i.e. land in different 64-byte halves (with the plain (r >> 1) & 7 they
+// shared one: 2-way conflicts on every ds_read_b64_tr_b16, 20 % of the LDS cycles in the counters).
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+    const int x = (row >> 1) & 7;
+    return row * HD + ((chunk ^ (((x & 1) << 2) | (x >> 1))) << 3);
+}
 
 // A operand = transpose of a row-major tile: rows = 16 tokens t0 .. t0+15 of k-step s (lane half h takes
 // tokens t0 + 4h + {0..3} and + 8), columns d = 32 dt + (lane & 31).

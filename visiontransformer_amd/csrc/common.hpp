@@ -58,7 +58,7 @@ __device__ __forceinline__ AttnTile attn_tile(int ntiles, int A) {
 }
 
 // ---- dropout: counter-based keep/drop decision (no state, identical in forward and backward) ----
-// keep(seed, stream, major, minor) = half[minor & 1](fmix32((minor >> 1) ^ fmix32(seed ^ stream*C1 ^ major*C2))) >= thresh,
+// keep(seed, stream, major, minor) = half[minor & 1](mix(minor >> 1, key)) >= thresh,  key = fmix32(seed ^ stream*C1 ^ major*C2),
 // thresh = round(p * 2^16): the low / high 16 bits of one hash serve the even / odd element of a pair.
 // `stream` = layer * 8 + site (0 embeddings, 1 attention probabilities, 2 attention output, 3 MLP output);
 // (major, minor) = (row, column) of the tensor, or (bh * N + query, key) for attention probabilities.
@@ -75,11 +75,24 @@ __host__ __device__ __forceinline__ unsigned fmix32(unsigned h) {
 __host__ __device__ __forceinline__ unsigned drop_key(unsigned seed, unsigned stream, unsigned major) {
     return fmix32(seed ^ (stream * 0x9E3779B1u) ^ (major * 0x85EBCA77u));
 }
+// low 24 bits of a times the 24-bit constant k, plus c (one v_mad_u32_u24: full rate, unlike the 32-bit multiply)
+__host__ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned k, unsigned c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, k) + c;
+#else
+    return (unsigned)(((unsigned long long)(a & 0xffffffu) * (k & 0xffffffu) + c) & 0xffffffffull);
+#endif
+}
 // One hash decides TWO neighbouring elements (minor = 2j, 2j + 1): 16 bits each against thresh = round(p * 2^16).
-// The kernels ask for the elements of a pair back to back, so the compiler keeps one fmix32 per pair -- hashing the
-// N x N attention probabilities three times per layer (forward + the two backward kernels) was 8 % of a training step.
+// The per-row key is a full fmix32 (once per row); the per-pair mixer is two 24-bit multiply-adds and two xor-shifts --
+// the attention kernels evaluate it for every element of the N x N probabilities in the forward and in both backward
+// kernels, where two 32-bit multiplies per hash (quarter rate) were ~ 5 ms of a training step.  Statistics (keep rate,
+// pair / neighbour / row / layer correlations, bit balance) are those of fmix32 (tests/test_host_cpu.py).
 __host__ __device__ __forceinline__ bool drop_keep(unsigned key, unsigned minor, unsigned thresh) {
-    const unsigned h = fmix32((minor >> 1) ^ key);
+    unsigned h = mad24(minor >> 1, 0x9E3779u, key);
+    h ^= h >> 15;
+    h = mad24(h, 0x85EBCBu, h >> 9);
+    h ^= h >> 14;
     return ((minor & 1u) ? (h >> 16) : (h & 0xffffu)) >= thresh;
 }
 struct DropArgs {

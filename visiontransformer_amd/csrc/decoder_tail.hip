@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 template <typename TargetT>
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ Z, const TargetT* __restrict__ target,
                                                       float* __restrict__ G, double* __restrict__ partial, int B, int C,
-                                                      int g, int S) {
+                                                      int g, int S, float gscale) {
     __shared__ double red[4];
     const size_t npx = (size_t)B * S * S;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
         const float lse = m + logf(ssum);
         local = (double)(lse - picked);
         if (G) {
-            const float inv = 1.0f / (float)npx;
+            const float inv = gscale / (float)npx;   // gscale: the upstream d(total loss) / d(this loss), e.g. 1 / accumulation
             for (int c = 0; c < C; ++c) {
                 const float pc = expf(logit(c) - lse);
                 G[(((size_t)b * C + c) * S + Y) * S + X] = (pc - (c == t ? 1.f : 0.f)) * inv;
@@ -246,15 +246,15 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const double* __restrict
 size_t ce_partial_count(int B, int S) { return ((size_t)B * S * S + 255) / 256; }
 
 int launch_ce_loss(const float* Z, const void* target, int target_is_u8, float* G, double* partial, float* loss, int B,
-                   int C, int g, int S, hipStream_t s) {
+                   int C, int g, int S, hipStream_t s, float gscale) {
     VITSEG_CHECK_ARG(Z && target && partial && loss, VITSEG_EINVAL, "ce_loss: null pointer");
     const unsigned nb = (unsigned)ce_partial_count(B, S);
     if (target_is_u8)
         hipLaunchKernelGGL(ce_loss_kernel<uint8_t>, dim3(nb), dim3(256), 0, s, Z, (const uint8_t*)target, G, partial, B,
-                           C, g, S);
+                           C, g, S, gscale);
     else
         hipLaunchKernelGGL(ce_loss_kernel<long long>, dim3(nb), dim3(256), 0, s, Z, (const long long*)target, G,
-                           partial, B, C, g, S);
+                           partial, B, C, g, S, gscale);
     VITSEG_LAUNCH_CHECK("ce_loss");
     hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, partial, (int)nb, 1.0 / ((double)B * S * S), loss);
     VITSEG_LAUNCH_CHECK("ce_finish");

@@ -104,7 +104,7 @@ int launch_upsample(const float* Z, float* logits, uint8_t* mask, int B, int C, 
 // CE loss on the (virtually) upsampled logits (a13); optional full-resolution gradient G
 size_t ce_partial_count(int B, int S);
 int launch_ce_loss(const float* Z, const void* target, int target_is_u8, float* G, double* partial, float* loss, int B,
-                   int C, int g, int S, hipStream_t s);
+                   int C, int g, int S, hipStream_t s, float gscale = 1.0f);
 
 // CLS token rows of the embedding output: X[B*Np + b] = cls + pos[0]  (a3)
 int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int Np, int D, hipStream_t s);

@@ -134,6 +134,7 @@ struct Ctx {
     bool lp;
     float drop_p = 0.f;
     unsigned drop_seed = 0;
+    float loss_scale = 1.f;   // multiplies the gradient of the fused CE loss (not the reported loss value)
     // dropout sites: 0 embeddings, 1 attention probabilities, 2 attention output, 3 MLP output (modeling_vit.py:159,184,276,283)
     DropArgs dr(int layer, int site) const {
         DropArgs d{};
@@ -288,7 +289,7 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
     const float* Gfull = grad_logits;
     if (target) {
         if ((rc = launch_ce_loss(c.T(c.p.z), target, target_is_u8, c.T(c.p.g), (double*)(c.ws + c.p.ce_partial), loss, B,
-                                 s.C, s.g, s.S, st)))
+                                 s.C, s.g, s.S, st, c.loss_scale)))
             return rc;
         Gfull = c.T(c.p.g);
     }
@@ -468,10 +469,11 @@ int vitseg_forward_train(const vitseg_config* cfg, const float* params, const vo
 
 int vitseg_backward(const vitseg_config* cfg, const float* params, const void* params_bf16, const float* x, int batch,
                     int precision, float dropout_p, uint64_t dropout_seed, const void* target, int target_is_u8,
-                    const float* grad_logits, float* grads, float* loss, void* const* bucket_events, void* workspace,
-                    size_t workspace_bytes, void* stream) {
+                    const float* grad_logits, float* grads, float* loss, float loss_scale, void* const* bucket_events,
+                    void* workspace, size_t workspace_bytes, void* stream) {
     Ctx c;
     c.events = bucket_events;
+    c.loss_scale = loss_scale;
     if (int rc = init_ctx(c, cfg, params, batch, precision, workspace, workspace_bytes, stream)) return rc;
     VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "dropout_p %f", dropout_p);
     c.drop_p = dropout_p;
@@ -511,7 +513,7 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const void* p
     const float* Gfull = grad_logits;
     if (target) {
         if ((rc = launch_ce_loss(c.T(c.p.z), target, target_is_u8, c.T(c.p.g), (double*)(c.ws + c.p.ce_partial), loss, B,
-                                 s.C, s.g, s.S, st)))
+                                 s.C, s.g, s.S, st, c.loss_scale)))
             return rc;
         Gfull = c.T(c.p.g);
     }

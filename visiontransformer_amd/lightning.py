@@ -31,21 +31,22 @@ class LightningViTModel(nn.Module):
         # classes.py:273-274 (host-side label preprocessing; nearest: idx = min(floor(dst*in/out), in-1))
         return F.interpolate(y.unsqueeze(1).float(), size=size, mode="nearest").squeeze(1).long()
 
-    def _loss(self, batch):
+    def _loss(self, batch, grad_scale=None):
         x, y = batch
         S = self.model.cfg.image_size  # the reference hard-codes (224, 224) = its image_size (classes.py:278)
         y = self._resize_target(y, size=(S, S))
-        return self.model.ce_loss(x, y)
+        return self.model.ce_loss(x, y, grad_scale=grad_scale)
 
-    def training_step(self, batch, batch_idx):
-        loss = self._loss(batch)
-        self.logged["train_loss"] = float(loss.detach())
+    # `logged` holds DEVICE scalars: reading one (float(...)) is the only host sync, and only the caller decides when
+    def training_step(self, batch, batch_idx, grad_scale=None):
+        loss = self._loss(batch, grad_scale)
+        self.logged["train_loss"] = loss.detach()
         return loss
 
     def validation_step(self, batch, batch_idx):
         with torch.no_grad():
             loss = self._loss(batch)
-        self.logged["valid_loss"] = float(loss)
+        self.logged["valid_loss"] = loss
         return loss
 
     def configure_optimizers(self):

@@ -43,19 +43,22 @@ class _LogitsFn(torch.autograd.Function):
 
 
 class _CELossFn(torch.autograd.Function):
-    """Fused CE: forward + loss + backward in one go (no [B,C,S,S] logits tensor is returned)."""
+    """Fused CE: forward + loss + backward in one go (no [B,C,S,S] logits tensor is returned).  With `grad_scale` the
+    factor is folded into the CE gradient at its source (vitseg_backward's loss_scale) and the upstream gradient of the
+    returned loss is taken to be 1: no arena-sized multiply, no second arena-sized temporary."""
 
     @staticmethod
-    def forward(ctx, arena, model, x, target):
+    def forward(ctx, arena, model, x, target, grad_scale):
         drop = model._next_dropout()
         model._forward_train(x, want_logits=False, drop=drop)
-        grads, loss = model._backward(x, target=target, drop=drop)
+        grads, loss = model._backward(x, target=target, drop=drop, loss_scale=1.0 if grad_scale is None else grad_scale)
         ctx.grads = grads
+        ctx.prescaled = grad_scale is not None
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        return ctx.grads * dloss, None, None, None
+        return (ctx.grads if ctx.prescaled else ctx.grads * dloss), None, None, None, None
 
 
 class ViTSegmentationModel(nn.Module):
@@ -77,6 +80,7 @@ class ViTSegmentationModel(nn.Module):
         self.grad_bucket_mb = 48.0
         self._buckets = None
         self._grads_reduced = False
+        self._require_sync = True
         self._graphs = {}   # (batch, with logits) -> captured hipGraph of the forward (predict_mask_graphed)
         n = _lib.param_count(self.cfg)  # validates the configuration (ValueError on unsupported shapes)
         self.arena = nn.Parameter(torch.zeros(n, dtype=torch.float32, device=device))
@@ -245,10 +249,29 @@ class ViTSegmentationModel(nn.Module):
                 torch.cuda.current_stream().cuda_stream))
         return logits
 
+    def no_sync(self):
+        """Context manager for gradient accumulation (what DDP's `no_sync` is for): backwards inside it only accumulate
+        locally; the all-reduce happens once, on the first backward outside (`dist.sync_grads` after it)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self._require_sync = self._require_sync, False
+            try:
+                yield
+            finally:
+                self._require_sync = old
+        return ctx()
+
     def _overlap_active(self) -> bool:
         """Bucketed all-reduce inside the backward: "overlap" = whenever a process group with > 1 rank exists,
-        "force" = also with one rank (tests), "after" = never (callers use dist.allreduce_grads)."""
+        "force" = also with one rank (tests), "after" = never (callers use dist.allreduce_grads).  Never inside
+        `no_sync()`, and never while a locally accumulated gradient is pending (`arena.grad` set): the kernels write
+        THIS micro-batch's gradient, the sum over micro-batches only exists after autograd has accumulated it, so that
+        step is reduced once, flat, by `dist.sync_grads`."""
         import torch.distributed as td
+        if not self._require_sync or self.arena.grad is not None:
+            return False
         if self.grad_sync == "force":
             return td.is_available() and td.is_initialized()
         return self.grad_sync == "overlap" and td.is_available() and td.is_initialized() and td.get_world_size() > 1
@@ -265,7 +288,7 @@ class ViTSegmentationModel(nn.Module):
         return self._buckets
 
     def _backward(self, x: torch.Tensor, target: Optional[torch.Tensor] = None,
-                  grad_logits: Optional[torch.Tensor] = None, drop=(0.0, 0)):
+                  grad_logits: Optional[torch.Tensor] = None, drop=(0.0, 0), loss_scale: float = 1.0):
         x = x.to(torch.float32).contiguous()
         B = x.shape[0]
         ws = self._train_workspace(B)
@@ -278,7 +301,7 @@ class ViTSegmentationModel(nn.Module):
                 C.byref(_lib.CConfig.from_config(self.cfg)), self.arena.data_ptr(), _ptr(self._bf16_arena()),
                 x.data_ptr(), B, self.precision, drop[0], drop[1],
                 _ptr(target), int(target is not None and target.dtype == torch.uint8), _ptr(grad_logits),
-                grads.data_ptr(), _ptr(loss), handles, ws.data_ptr(), ws.numel(),
+                grads.data_ptr(), _ptr(loss), float(loss_scale), handles, ws.data_ptr(), ws.numel(),
                 torch.cuda.current_stream().cuda_stream))
             if overlap:
                 # the whole backward is enqueued by now; each ring starts when its bucket's event fires and the
@@ -355,15 +378,18 @@ class ViTSegmentationModel(nn.Module):
         m = self.predict_mask(tiles)
         return m.reshape(B, ty, tx, S, S).permute(0, 1, 3, 2, 4).reshape(B, H, W).contiguous()
 
-    def ce_loss(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    def ce_loss(self, x: torch.Tensor, target: torch.Tensor, grad_scale: Optional[float] = None) -> torch.Tensor:
         """`nn.CrossEntropyLoss()(self(x), target)` (model/CE/classes.py:268,280) as a device scalar, without
         materialising the [B, C, S, S] logits: forward to the low-res map, then the fused upsample+CE kernel.
-        `target`: class indices [B, S, S], torch.long (reference) or torch.uint8, on the model's device."""
+        `target`: class indices [B, S, S], torch.long (reference) or torch.uint8, on the model's device.
+        `grad_scale` (optional): the gradient `loss.backward()` deposits is grad_scale * d loss / d params, folded into
+        the CE gradient inside the kernel (e.g. 1 / accumulate_grad_batches); call `.backward()` on the returned loss
+        itself then -- an upstream factor is ignored in this mode."""
         S, B = self.cfg.image_size, x.shape[0]
         if tuple(target.shape) != (B, S, S) or target.dtype not in (torch.int64, torch.uint8):
             raise ValueError(f"target must be int64/uint8 [B, {S}, {S}], got {target.dtype} {tuple(target.shape)}")
         if self._needs_grad():
-            return _CELossFn.apply(self.arena, self, x, target.to(self.arena.device).contiguous())
+            return _CELossFn.apply(self.arena, self, x, target.to(self.arena.device).contiguous(), grad_scale)
         with torch.no_grad():
             _, _ = self._run(x, False, True)  # fills the low-res logits (mask output is a by-product)
             low = self.debug_buffer(B, _lib.BUF_LOWRES)

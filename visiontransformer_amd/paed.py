@@ -1,11 +1,11 @@
 """PAED entry points of the reference (model/PAED/classes.py) on the MI355X model.
 
 `ViTSegmentationModel` is the same class as in model/CE (the reference keeps a byte-identical copy at
-model/PAED/classes.py:372-413); what differs is the loss tail.  The 17-class soft
-PAED loss and its gradient are libvitseg kernels (`paed_multiclass_loss_fused`, csrc/paed_loss.hip); the binary
-trainer's BCE + Dice + Sobel/SDF tail is elementwise / small-stencil maths that still runs as PyTorch-ROCm tensor
-ops on the logits.  Either way the gradient reaches the parameters through libvitseg's backward (`vitseg_backward`
-with `grad_logits`).  Lightning's logging is replaced by a `logged` dict.  The plain-torch functions below
+model/PAED/classes.py:372-413); what differs is the loss tail.  Both tails and their
+gradients are libvitseg kernels: the 17-class soft PAED loss (`paed_multiclass_loss_fused`, csrc/paed_loss.hip) and the
+binary trainer's sigmoid + BCE + Dice + SDF-resize + Sobel + per-image max-normalised edge term
+(`paed_binary_loss_fused`, csrc/paed_binary.hip).  Either way the gradient reaches the parameters through libvitseg's
+backward (`vitseg_backward` with `grad_logits`).  Lightning's logging is replaced by a `logged` dict.  The plain-torch functions below
 (`paed_loss_multiclass_soft`, ...) mirror the reference's free functions of the same names.
 
   * `LightningViTModel` -- 17-class soft-PAED loss, Adam(lr=1e-4)          (model/PAED/classes.py:415-487)
@@ -78,6 +78,46 @@ def paed_multiclass_loss_fused(logits, target, sigma=3, class_penalty=True):
     return _PAEDMulticlassFn.apply(logits, target, sigma, class_penalty)
 
 
+class _PAEDBinaryFn(torch.autograd.Function):
+    """sigmoid + BCE + 0.1 Dice + 5 |soft PAED| and d loss / d logits in three launches (csrc/paed_binary.hip)."""
+
+    @staticmethod
+    def forward(ctx, logits, mask, sdf_ext, sdf_int):
+        from . import _lib
+        logits = logits.contiguous().float()
+        B, one, H, W = logits.shape
+        if one != 1:
+            raise ValueError(f"the binary PAED trainer expects [B, 1, H, W] logits, got {tuple(logits.shape)}")
+        mask = mask.reshape(B, H, W).contiguous().float()
+        sdf_ext, sdf_int = sdf_ext.contiguous().float(), sdf_int.contiguous().float()
+        hs, ws = sdf_ext.shape[-2:]
+        if tuple(sdf_int.shape[-2:]) != (hs, ws) or sdf_ext.numel() != B * hs * ws or sdf_int.numel() != B * hs * ws:
+            raise ValueError("sdf_ext / sdf_int must be [B, h, w] maps of one size")
+        L = _lib.lib()
+        scratch = torch.empty(L.vitseg_paed_binary_scratch_bytes(B, H, W), dtype=torch.uint8, device=logits.device)
+        out = torch.empty(8, dtype=torch.float32, device=logits.device)
+        grad = torch.empty_like(logits) if logits.requires_grad else None
+        with torch.cuda.device(logits.device):
+            _lib.check(L.vitseg_paed_binary_loss(logits.data_ptr(), mask.data_ptr(), sdf_ext.data_ptr(), sdf_int.data_ptr(),
+                                                 hs, ws, B, H, W, scratch.data_ptr(), out.data_ptr(),
+                                                 None if grad is None else grad.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream))
+        ctx.grad = grad
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_terms):
+        return ctx.grad * grad_loss, None, None, None
+
+
+def paed_binary_loss_fused(logits, mask, sdf_ext, sdf_int):
+    """`F.binary_cross_entropy(p, mask) + 0.1 * dice_loss(p, mask) + 5 * |paed_loss_soft(sdf_ext, sdf_int, p)|` with
+    p = sigmoid(logits) (model/PAED/classes.py:664-681), on the device in one fused call; differentiable w.r.t. `logits`
+    [B, 1, H, W].  Returns (loss, terms) with terms = [loss, bce, dice, paed, tp, fp, fn, equal] (device floats)."""
+    return _PAEDBinaryFn.apply(logits, mask, sdf_ext, sdf_int)
+
+
 def dice_loss(preds, targets, smooth=1e-6):
     """1 - (2 |P.T| + s) / (|P| + |T| + s) on the flattened batch (model/PAED/classes.py:608-620)."""
     p, t = preds.float().reshape(-1), targets.float().reshape(-1)
@@ -148,8 +188,8 @@ class LightningViTModel(_Base):
         logits = self.forward(x)
         # softmax + one-hot + blur + weighting and their gradient run in libvitseg (csrc/paed_loss.hip)
         loss = paed_multiclass_loss_fused(logits, y)
-        self.logged[f"{tag}_loss"] = float(loss.detach())
-        self.logged[f"{tag}_iou"] = float(iou_score(logits.detach().argmax(dim=1), y, self.num_classes))  # argmax(softmax) = argmax
+        self.logged[f"{tag}_loss"] = loss.detach()                   # device scalars: no host sync per step
+        self.logged[f"{tag}_iou"] = iou_score(logits.detach().argmax(dim=1), y, self.num_classes)  # argmax(softmax) = argmax
         return loss
 
     def training_step(self, batch, batch_idx):
@@ -169,19 +209,18 @@ class PAEDTrainer(_Base):
 
     def _forward_step_paed(self, batch, batch_idx, tag="train"):
         images, masks, sdf_ext, sdf_int = batch
-        masks = self._resize_target(masks).unsqueeze(1).float()
-        preds = torch.sigmoid(self.forward(images))
-        paed = paed_loss_soft(sdf_ext.unsqueeze(1), sdf_int.unsqueeze(1), preds)
-        loss = F.binary_cross_entropy(preds, masks) + 0.1 * dice_loss(preds, masks) + 5.0 * paed.abs()  # :679-681
+        masks = self._resize_target(masks).float()
+        # sigmoid, BCE + 0.1 Dice + 5 |soft PAED| (:679-681), their gradient and the confusion counts: csrc/paed_binary.hip
+        loss, terms = paed_binary_loss_fused(self.forward(images), masks, sdf_ext, sdf_int)
         with torch.no_grad():
-            b, m = (preds > 0.5).float(), masks
-            tp, fp, fn = (b * m).sum(), (b * (1 - m)).sum(), ((1 - b) * m).sum()
-            acc = (b == m).float().mean()
+            tp, fp, fn, eq = terms[4], terms[5], terms[6], terms[7]
+            acc = eq / masks.numel()
             iou = tp / (tp + fp + fn).clamp_min(1e-12)
             dice = 2 * tp / (2 * tp + fp + fn).clamp_min(1e-12)
             prec, rec = tp / (tp + fp).clamp_min(1e-12), tp / (tp + fn).clamp_min(1e-12)
-        for k, v in dict(loss=loss, acc=acc, IoU=iou, dice=dice, precision=prec, recall=rec).items():
-            self.logged[f"{tag}_{k}"] = float(v.detach())
+        # device scalars: nothing here forces a host sync per step (read them with float() when a value is wanted)
+        self.logged.update({f"{tag}_loss": loss.detach(), f"{tag}_acc": acc, f"{tag}_IoU": iou, f"{tag}_dice": dice,
+                            f"{tag}_precision": prec, f"{tag}_recall": rec})
         return loss, acc, iou, dice, prec, rec
 
     def training_step(self, batch, batch_idx):
