@@ -260,3 +260,17 @@ def test_paed_binary_fused_matches_torch_autograd(B, H, W, hs, ws):
     assert abs(float(terms[3]) - pa.item()) < 5e-6
     gr = zd.grad.numpy() * 2.0
     assert np.abs(lg.grad.cpu().numpy() - gr).max() < 2e-5 * np.abs(gr).max() + 1e-12
+
+
+# ---------------------------------------------------------------- the reference's script entry points (model/CE, model/PAED)
+def test_reference_entry_points_run_end_to_end():
+    """tools/entrypoints_smoke.sh: testViTModel / trainCurrentViTmodel / createViTmodel / datasetTestViTmodel (CE) and
+    ViTscript / ViTscriptUp (resume from the checkpoint it just wrote) / ViTscriptTest (PAED) on synthetic data, each in
+    its own process from a scratch directory; the evaluation drivers must leave the CSV schema compareModels.py reads."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "entrypoints_smoke.sh")], cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "entry points ok" in r.stdout
+    assert "Model_ID,Model_Name,Patch_Size,Hidden_Size,Layers,Heads,Batch_Num,Image_Idx,Accuracy,Mean_IoU,Mean_Dice" in r.stdout
