@@ -28,9 +28,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
-// H: format tag of the 16-bit storage (bf16_t or f16_t, common.hpp H16<>); pointers are raw 16-bit words
-template <bool RAGGED, typename H>
-__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+// H: format tag of the 16-bit storage (bf16_t or f16_t, common.hpp H16<>); pointers are raw 16-bit words.
+// DROP: attention-probability dropout compiled in (training); RAGGED: Np is not a multiple of the 128-query block.
+// Online softmax with a DEFERRED maximum: the S accumulators start at -m (the running maximum, raw score units), so
+// p = exp2(c * acc) with no subtraction; m only moves -- and O, l are only rescaled -- when some score exceeds it by more
+// than 8 / c, i.e. p > 2^8 (wave-uniform, rare after the first tiles): P stays <= 256, exact in the fp32 sums and harmless
+// in the 16-bit P.  (Prescaling q by c instead would save the multiply too, but a second rounding of q to the 16-bit
+// format costs accuracy on peaked rows: measured 0.041 vs 0.03 max error in the op test; it belongs into the QKV
+// projection's epilogue, before the first rounding.)
+constexpr float DEFER_THR = 8.0f;
+template <bool DROP, bool RAGGED, typename H>
+__global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ lse, int B, int Np, int A,
                                                            DropArgs dr) {
     // [buffer][K|V][key * 64 + d] bf16, rows of 128 B with XOR-swizzled 16-B chunks: 32 KiB
@@ -50,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 
     // ---- this lane's query row: k-step s holds Q[16 s + 8 lh .. +7] (B operand of S^T) ----
     const int q_local = at.rt * QB + wave * 32 + li;
-    const bool q_valid = q_local < Np;
+    const bool q_valid = !RAGGED || q_local < Np;
     const size_t q_row = row0 + (q_valid ? q_local : Np - 1);
     f32x4 qf[4];
 #pragma unroll
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
                 o[dt][4 * g4 + 2] = H16<H>::lo(t.y);
                 o[dt][4 * g4 + 3] = H16<H>::hi(t.y);
             }
-        if (dr.thresh) {
+        if (DROP) {
             const float kc = drop_keep(dkey, (unsigned)Np, dr.thresh) ? dr.scale : 0.f;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -131,16 +139,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         gload(min(kt + 1, nkt - 1));  // the last tile re-stages itself: keeps the body branch-free
-        __builtin_amdgcn_sched_barrier(0);
         const bf16_t* Ks = lds[buf][0];
         const bf16_t* Vs = lds[buf][1];
 
-        // S^T[key][query], two blocks of 32 keys
+        // S^T[key][query] - m, two blocks of 32 keys
         f32x16 st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) st[kb][r] = -m_run;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f32x4 kf = *(const f32x4*)&Ks[kb * 32 * HD + k_off + (((2 * s + lh) ^ k_sw) << 3)];
@@ -158,29 +165,32 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
         for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, st[0][r]), st[1][r]);  // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        // the running maximum settles after the first few key tiles: rescale O and l only when some lane's
-        // maximum actually grew (wave-uniform branch), otherwise alpha == 1 exactly and the work is skipped
-        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        // the running maximum settles after the first few key tiles: m, O and l move only when some lane's scores
+        // exceed it by more than the threshold (wave-uniform branch)
+        if (__builtin_amdgcn_ballot_w64(mx > DEFER_THR * (1.0f / (0.125f * LOG2E))) != 0) {
+            const float delta = fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta * c);
             l_run *= alpha;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-            m_run = m_new;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kb][r] -= delta;
+            m_run += delta;
         }
-        const float mc = m_run * c;
         float psum = 0.f;
         unsigned pk[2][8];  // P^T fragments: pk[kb][4 s + w] = registers 8 s + 2 w, 8 s + 2 w + 1
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, -mc));
-                float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c, -mc));
+                float p0 = __builtin_amdgcn_exp2f(st[kb][r] * c);
+                float p1 = __builtin_amdgcn_exp2f(st[kb][r + 1] * c);
                 psum += p0 + p1;
-                if (dr.thresh) {
+                if (DROP) {
                     const unsigned k0 = (unsigned)(kt * KB + kb * 32);
                     p0 = drop_keep(dkey, k0 + kappa(r, lh), dr.thresh) ? p0 * dr.scale : 0.f;
                     p1 = drop_keep(dkey, k0 + kappa(r + 1, lh), dr.thresh) ? p1 * dr.scale : 0.f;
@@ -339,12 +349,15 @@ template <typename H>
 static int launch_attention_h16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_bf16: bad arguments");
     const dim3 grid((unsigned)((Np + QB - 1) / QB) * A * B);  // 1-D: attn_tile() places the tiles
-    if (Np % QB == 0)
-        hipLaunchKernelGGL((attn_bf16_kernel<false, H>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B,
-                           Np, A, dr);
-    else
-        hipLaunchKernelGGL((attn_bf16_kernel<true, H>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B,
-                           Np, A, dr);
+    const bool ragged = Np % QB != 0, drop = dr.thresh != 0;
+#define VITSEG_ATTN_LAUNCH(DR, RG)                                                                                       \
+    hipLaunchKernelGGL((attn_bf16_kernel<DR, RG, H>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B, Np, A, dr)
+    if (drop) {
+        if (ragged) VITSEG_ATTN_LAUNCH(true, true); else VITSEG_ATTN_LAUNCH(true, false);
+    } else {
+        if (ragged) VITSEG_ATTN_LAUNCH(false, true); else VITSEG_ATTN_LAUNCH(false, false);
+    }
+#undef VITSEG_ATTN_LAUNCH
     VITSEG_LAUNCH_CHECK("attn_bf16");
     const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 64 * 64) * sizeof(float);
     VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_bf16: sequence too long for the CLS kernel");

@@ -816,31 +816,23 @@ constexpr int LBM = 256;
 // LBN = 128: waves 4(M) x 2(N), 64x64 per wave, 3-stage ring (3 x 48 KiB), 85 FLOP per staged byte.
 // LBN = 256: waves 2(M) x 4(N), 128x64 per wave (128 accumulator registers), 2-stage ring (2 x 64 KiB),
 //            128 FLOP per staged byte -- half the L2->LDS traffic of the 128x128 kernel, which is what bounds it.
-// LBN = 256, WAVES = 4: waves 2(M) x 2(N), 128x128 per wave (256 accumulator registers, ONE wave per SIMD with the
-//            whole 512-register file).  At 32 clk per 32x32x16 MFMA a wave tile of MI x NI blocks reads
-//            (MI + NI) KiB of fragments per MI * NI MFMAs; with the four matrix pipes of a CU busy that is
-//            128 * (MI + NI) / (MI * NI) bytes/clk of LDS reads against a 128 B/clk LDS: 2x2 tiles need all of it
-//            (the 128x128 kernel's ~50 % ceiling), 4x2 needs 96, 4x4 needs 64.  Measured (tools/tile_sweep.sh): correct, but
-//            7-11 % SLOWER than the 8-wave 256x256 tile on every model shape -- with a single wave per SIMD nothing
-//            covers its barrier and LDS-latency stalls.  Kept selectable (VITSEG_BF16_TILES=4w) as the starting point
-//            of a finer-phased pipeline; never picked by default.
-template <typename T, typename OutT, int AMODE, int EPI, int LBN, int WAVES = 8>
-__global__ __launch_bounds__(WAVES * 64) void gemm_bf16_large_kernel(const GemmArgs p) {
+template <typename T, typename OutT, int AMODE, int EPI, int LBN>
+__global__ __launch_bounds__(512) void gemm_bf16_large_kernel(const GemmArgs p) {
     constexpr int CE = 8, BKE = 64, BK = BKF;
     constexpr int STAGES = LBN == 128 ? 3 : 2;
-    constexpr int MI = LBN == 128 ? 2 : 4, NI = WAVES == 4 ? 4 : 2;      // 32x32 MFMA tiles per wave
+    constexpr int WAVES = 8;
+    constexpr int MI = LBN == 128 ? 2 : 4, NI = 2;      // 32x32 MFMA tiles per wave
     constexpr int WROWS = MI * 32;                       // rows per wave
     constexpr int APW = LBM / 8 / WAVES;                 // A DMA pieces per wave (8 rows each)
     constexpr int WPW = LBN / 8 / WAVES;                 // W DMA pieces per wave
-    static_assert(WAVES == 8 || (WAVES == 4 && LBN == 256), "4 waves: the 256x256 tile only");
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [stage][A 256 rows | W LBN rows][32 words]
     auto stageA = [&](int st) { return lds_raw + st * (LBM + LBN) * BK; };
     auto stageW = [&](int st) { return lds_raw + st * (LBM + LBN) * BK + LBM * BK; };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches below
-    const int wm = WAVES == 4 ? wave >> 1 : (LBN == 128 ? wave >> 1 : wave >> 2);
-    const int wn = WAVES == 4 ? wave & 1 : (LBN == 128 ? wave & 1 : wave & 3);
+    const int wm = LBN == 128 ? wave >> 1 : wave >> 2;
+    const int wn = LBN == 128 ? wave & 1 : wave & 3;
     const int tiles_n = (p.N + LBN - 1) / LBN, tiles_m = (p.M + LBM - 1) / LBM;
     int t = xcd_remap(blockIdx.x, gridDim.x);
     const int GN = p.gn ? p.gn : (LBN == 128 ? ((size_t)p.K * sizeof(T) <= 2048 ? 8 : 4) : 4);
@@ -1076,7 +1068,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_large_kernel(const GemmA
     }
 }
 
-template <typename T, typename OutT, int AMODE, int EPI, int LBN = 128, int WAVES = 8>
+template <typename T, typename OutT, int AMODE, int EPI, int LBN = 128>
 int launch_large(GemmArgs a, hipStream_t s) {
     if (a.ldw == 0) a.ldw = a.K;
     if (!a.gn) a.gn = env_gn();
@@ -1084,12 +1076,12 @@ int launch_large(GemmArgs a, hipStream_t s) {
     const size_t smem = (size_t)(LBN == 128 ? 3 : 2) * (LBM + LBN) * BKF * sizeof(float);  // 144 / 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN, WAVES>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_large)");
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN, WAVES>), dim3(tiles), dim3(WAVES * 64), smem, s, a);
+    hipLaunchKernelGGL((gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN>), dim3(tiles), dim3(512), smem, s, a);
     VITSEG_LAUNCH_CHECK("gemm_bf16_large");
     return VITSEG_OK;
 }
@@ -1209,26 +1201,22 @@ int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
             default: return launch_one<T, float, A_PLAIN, EPI_RESADD>(t, s);
         }
     }
-    const char* force = getenv("VITSEG_BF16_TILES");  // "large" / "xl" / "4w" (256x256, 4 waves) / "small" for experiments
-    const bool w4 = force && force[0] == '4';
+    const char* force = getenv("VITSEG_BF16_TILES");  // "large" / "xl" / "small" for experiments
     const bool xl = force ? force[0] == 'x' : (a.M >= 8192 && a.N >= 2048);
     const bool large = force ? force[0] == 'l' : (!xl && a.M >= 4096 && a.K >= 2048);
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 8 == 0, VITSEG_EINVAL, "gemm_bf16: lda %% 8");
         switch (epi) {
-            case EPI_BIAS: return w4 ? launch_large<T, T, A_PLAIN, EPI_BIAS, 256, 4>(a, s)
-                                  : xl ? launch_large<T, T, A_PLAIN, EPI_BIAS, 256>(a, s)
+            case EPI_BIAS: return xl ? launch_large<T, T, A_PLAIN, EPI_BIAS, 256>(a, s)
                                   : large ? launch_large<T, T, A_PLAIN, EPI_BIAS>(a, s)
                                           : launch_one<T, T, A_PLAIN, EPI_BIAS>(a, s);
-            case EPI_GELU: return w4 ? launch_large<T, T, A_PLAIN, EPI_GELU, 256, 4>(a, s)
-                                  : xl ? launch_large<T, T, A_PLAIN, EPI_GELU, 256>(a, s)
+            case EPI_GELU: return xl ? launch_large<T, T, A_PLAIN, EPI_GELU, 256>(a, s)
                                   : large ? launch_large<T, T, A_PLAIN, EPI_GELU>(a, s)
                                           : launch_one<T, T, A_PLAIN, EPI_GELU>(a, s);
             case EPI_DGELU: return xl ? launch_large<T, T, A_PLAIN, EPI_DGELU, 256>(a, s)
                                    : large ? launch_large<T, T, A_PLAIN, EPI_DGELU>(a, s)
                                            : launch_one<T, T, A_PLAIN, EPI_DGELU>(a, s);
-            case EPI_RESADD: return w4 ? launch_large<T, float, A_PLAIN, EPI_RESADD, 256, 4>(a, s)
-                                    : xl ? launch_large<T, float, A_PLAIN, EPI_RESADD, 256>(a, s)
+            case EPI_RESADD: return xl ? launch_large<T, float, A_PLAIN, EPI_RESADD, 256>(a, s)
                                     : large ? launch_large<T, float, A_PLAIN, EPI_RESADD>(a, s)
                                             : launch_one<T, float, A_PLAIN, EPI_RESADD>(a, s);
         }

@@ -57,7 +57,9 @@ def fit(model, train_batches: Iterable, val_batches: Optional[Iterable] = None, 
         pending = []
         for i, batch in enumerate(train_batches):
             batch = tuple(t.to(device) for t in batch)
-            last = (n_micro + 1) % accumulate_grad_batches == 0
+            # Lightning also steps on the epoch's final batch when the accumulation window is incomplete
+            n_total = len(train_batches) if hasattr(train_batches, "__len__") else None
+            last = (n_micro + 1) % accumulate_grad_batches == 0 or (n_total is not None and i + 1 == n_total)
             # every micro-batch loss is scaled by 1 / accumulate (Lightning does the same); all but the last backward of
             # an optimizer step stay local
             with (contextlib.nullcontext() if last else net.no_sync()):
