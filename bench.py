@@ -40,26 +40,37 @@ KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
             "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0, 0>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
             "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 0>",
             "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
-    "bf16": {"gemm_bias": "gemm_bf16_large_kernel<unsigned short, unsigned short, 0, 0, 256, 8>",
-             "gemm_gelu": "gemm_bf16_large_kernel<unsigned short, unsigned short, 0, 1, 256, 8>",
-             "gemm_resadd": "gemm_kernel<unsigned short, float, 0, 2, 0, 0, 0> (o_proj) + "
-                            "gemm_bf16_large_kernel<unsigned short, float, 0, 2, 128, 8> (fc2)",
+    # 16-bit operands: the 8-phase persistent kernel gemm_p8_kernel<T, OutT, EPI, TT> (csrc/gemm_p8.hip) whenever
+    # M >= 2048, N % 256 == 0, K % 128 == 0 -- every encoder linear at the bench batch sizes
+    "bf16": {"gemm_bias": "gemm_p8_kernel<unsigned short, unsigned short, 0, 0>",
+             "gemm_gelu": "gemm_p8_kernel<unsigned short, unsigned short, 1, 0>",
+             "gemm_resadd": "gemm_p8_kernel<unsigned short, float, 2, 0>",
              "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
-             "gemm_conv3": "gemm_bf16_large_kernel<unsigned short, float, 2, 3, 128, 8>",
-             "attention": "attn_bf16_kernel<false, unsigned short> + attn_cls_bf16_kernel<unsigned short>"},
+             "gemm_conv3": "gemm_bf16_large_kernel<unsigned short, float, 2, 3, 128>",
+             "attention": "attn_bf16_kernel<false, false, unsigned short> + attn_cls_bf16_kernel<unsigned short>"},
     "f32x3": {"gemm_bias": "gemm_kernel<float, float, 0, 0, 0, 0, 2>", "gemm_gelu": "gemm_kernel<float, float, 0, 1, 0, 0, 2>",
               "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0, 2>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 2>",
               "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 2>",
               "attention": "attn_x3_kernel<false> + attn_cls_f32_kernel"},
     # rocprofv3's demangler does not know _Float16 (DF16_): the IEEE-half instantiations appear mangled in its CSVs
-    "f16": {"gemm_bias": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_DF16_Li0ELi0ELi256ELi8EEEvNS_8GemmArgsE",
-            "gemm_gelu": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_DF16_Li0ELi1ELi256ELi8EEEvNS_8GemmArgsE",
-            "gemm_resadd": "_ZN6vitseg12_GLOBAL__N_111gemm_kernelIDF16_fLi0ELi2ELi0ELi0ELi0EEEvNS_8GemmArgsE (o_proj) + "
-                           "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi0ELi2ELi128ELi8EEEvNS_8GemmArgsE (fc2)",
+    "f16": {"gemm_bias": "_ZN6vitseg14gemm_p8_kernelIDF16_DF16_Li0ELi0EEEvNS_8GemmArgsE",
+            "gemm_gelu": "_ZN6vitseg14gemm_p8_kernelIDF16_DF16_Li1ELi0EEEvNS_8GemmArgsE",
+            "gemm_resadd": "_ZN6vitseg14gemm_p8_kernelIDF16_fLi2ELi0EEEvNS_8GemmArgsE",
             "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
-            "gemm_conv3": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi2ELi3ELi128ELi8EEEvNS_8GemmArgsE",
-            "attention": "_ZN6vitseg12_GLOBAL__N_116attn_bf16_kernelILb0EDF16_EEvPKtPtPfiiiNS_8DropArgsE + "
+            "gemm_conv3": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi2ELi3ELi128EEEvNS_8GemmArgsE",
+            "attention": "_ZN6vitseg12_GLOBAL__N_116attn_bf16_kernelILb0ELb0EDF16_EEvPKtPtPfiiiNS_8DropArgsE + "
                          "_ZN6vitseg12_GLOBAL__N_120attn_cls_bf16_kernelIDF16_EEvPKtPtPfiiiNS_8DropArgsE"},
+    # training step (--mode train): kernel groups bracketed by the VITSEG_K_TRAIN_* scopes (csrc/vitseg_train.hip)
+    "train_bf16": {"train_gemm_fwd": "gemm_p8_kernel<unsigned short, *, {0,1,2}, 0> (the four forward linears)",
+                   "train_dgrad": "gemm_p8_kernel<unsigned short, *, {0,5}, 0> + transpose_bf16_kernel (activation gradients)",
+                   "train_wgrad": "gemm_p8_kernel<unsigned short, float, 0, 1> + splitk_reduce_kernel (weight gradients)",
+                   "train_attn_fwd": "attn_bf16_kernel<true, false, unsigned short> + attn_cls_bf16_kernel<unsigned short>",
+                   "train_attn_bwd": "attn_bwd_dkv_bf16_kernel<true, false> + attn_bwd_dq_bf16_kernel<true, false> + "
+                                     "attn_bwd_cls_bf16_kernel<true> + attn_delta_bf16_kernel"},
+    "train_f32": {"train_gemm_fwd": "gemm_kernel<float, float, 0, {0,1,2}, ...>", "train_dgrad": "gemm_kernel<float, float, ...> (W T-form)",
+                  "train_wgrad": "gemm_kernel<float, float, ...> (both T-form, split-K)",
+                  "train_attn_fwd": "attn_f32_kernel<true> + attn_cls_f32_kernel",
+                  "train_attn_bwd": "attn_bwd_dq_f32_kernel + attn_bwd_dkv_f32_kernel"},
 }
 
 
@@ -76,10 +87,10 @@ def algorithmic_bytes(precision, kind, cfg, batch):
 
 
 def pmc_traffic(precision, kernel_label, batch):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_traffic.sh ->
-    tools/summarize_traffic.py -> profiles/r01_traffic_<prec>.json): counters cannot be read from inside this process,
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_pmc.sh bench_<prec> ... ->
+    tools/summarize_traffic.py -> profiles/r02_traffic_<prec>.json): counters cannot be read from inside this process,
     so the figure is the one rocprofv3 measured on this same command (batch 32).  None when no pass covers the run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_traffic_{precision}.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_traffic_{precision}.json")
     if batch != 32 or not os.path.exists(path):
         return None
     kernels = json.load(open(path))["kernels"]
@@ -317,6 +328,16 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-kernel-group device time: hipEvents on the launch stream around the GEMM / attention launches of PROF_STEPS
+    # further steps of the same loop (outside the timed region, so the event records do not perturb `value`)
+    PROF_STEPS = 3
+    _lib.profile_enable(True)
+    for _ in range(PROF_STEPS):
+        step()
+    torch.cuda.synchronize()
+    prof = {k: v for k, v in _lib.profile_collect().items() if k.startswith("train_")}
+    _lib.profile_enable(False)
+    barrier()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -325,6 +346,10 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
     if rank == 0:
         value = world * B * args.steps / elapsed
         flops_img = 3.0 * cfg.forward_flops_per_image()
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        d = prof[dom]
+        dom_tflops = d["work"] / (d["ms"] * 1e-3) / 1e12
+        names = KERNEL_NAMES.get("train_" + ("f32" if args.precision == "f32" else "bf16"), {})
         peak = PEAK_TFLOPS[args.precision]
         print(json.dumps({
             "metric": "images/sec (512×512) ViT-B/16 seg, 1/2/4/8 MI355X + mask argmax match",
@@ -335,11 +360,16 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
                                    f"512x512, {args.precision}, dropout {model.dropout} (reference: 0.1)", "batch_per_gpu": B,
                        "global_batch": B * world,
                        "parallelism": f"data-parallel x{world}, bucketed gradient all-reduce (RCCL) overlapped with the backward"},
-            # the step is ~100 MFMA kernel kinds; the roofline here is the whole step's algorithmic FLOPs (3 x forward)
-            # over its wall time, per-kernel times are in profiles/r01_bench_train_*_kernel_stats.csv
-            "roofline": {"bound": "mfma", "achieved": round(value / world * flops_img / 1e12, 2), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(value / world * flops_img / 1e12 / peak, 4), "traffic": None,
-                         "kernel": "whole training step (forward + CE + backward + Adam)"},
+            # dominant kernel group of the step (largest summed device time): algorithmic FLOPs / hipEvent time on the
+            # launch stream; per-kernel times of the same command: profiles/r02_bench_train_*_kernel_stats.csv
+            "roofline": {"bound": "mfma", "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(dom_tflops / peak, 4), "traffic": None, "kernel": names.get(dom, dom),
+                         "launches": d["launches"], "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
+                         "flops_per_launch": d["work"] / max(d["launches"], 1)},
+            "kernel_groups": {k: {"ms_per_step": round(v["ms"] / PROF_STEPS, 3),
+                                  "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None,
+                                  "frac": round(v["work"] / (v["ms"] * 1e-3) / 1e12 / peak, 4) if v["ms"] > 0 else None}
+                              for k, v in prof.items()},
             "whole_model": {"flops_per_image": flops_img,
                             "achieved_tflops_per_gpu": round(value / world * flops_img / 1e12, 2),
                             "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},

@@ -286,7 +286,8 @@ int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, 
 
 /* ---- measurement hooks (bench.py's roofline object) ----
  * While enabled, vitseg_forward brackets every kernel launch of the hot path with a pair of
- * hipEvents on the launch stream.  vitseg_profile_collect synchronises those events (the only
+ * hipEvents on the launch stream; vitseg_forward_train / vitseg_backward bracket the GEMMs and
+ * the attention kernels of the encoder layers (the VITSEG_K_TRAIN_* kinds).  vitseg_profile_collect synchronises those events (the only
  * call in this library that blocks) and returns, for one kernel kind, the summed device time,
  * the number of launches and the algorithmic work of those launches (FLOPs for the MFMA kinds,
  * HBM bytes for the bandwidth-bound kinds).  Process-global and not re-entrant: a debugging
@@ -301,6 +302,12 @@ enum vitseg_kernel_kind {
     VITSEG_K_LAYERNORM,     /* bytes */
     VITSEG_K_HEAD1X1,       /* bytes */
     VITSEG_K_UPSAMPLE,      /* bytes */
+    /* training step (vitseg_forward_train / vitseg_backward), encoder layers only: FLOPs */
+    VITSEG_K_TRAIN_GEMM_FWD, /* the four forward linears of a layer */
+    VITSEG_K_TRAIN_DGRAD,    /* activation-gradient GEMMs (incl. the weight transposes they consume) */
+    VITSEG_K_TRAIN_WGRAD,    /* weight-gradient GEMMs (incl. their split-K reduction) */
+    VITSEG_K_TRAIN_ATTN_FWD, /* attention forward (patch + CLS query kernels) */
+    VITSEG_K_TRAIN_ATTN_BWD, /* attention backward (delta, dQ, dK/dV, CLS kernels) */
     VITSEG_K_COUNT
 };
 int vitseg_profile_enable(int on);

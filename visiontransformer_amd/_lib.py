@@ -37,7 +37,7 @@ EXPORTS = [
     "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
-                "head1x1", "upsample"]
+                "head1x1", "upsample", "train_gemm_fwd", "train_dgrad", "train_wgrad", "train_attn_fwd", "train_attn_bwd"]
 
 
 class CConfig(C.Structure):

@@ -101,21 +101,28 @@ __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __rest
 //   dx = rstd * (gw - mean(gw) - xhat * mean(gw * xhat));   dw = sum_rows g * xhat;   db = sum_rows g.
 // dres_out[row] = (dres_in ? dres_in[row] : 0) + dx  (the residual branch's gradient is added here).
 // One wave per row (statistics recomputed from the saved input), 64 rows per block; the block's dw/db
-// partial sums go to partial[block][2][D].
-template <int NV, typename GT>
+// partial sums go to partial[block][SETS][D].
+// BR (branch output): the gradient that enters the NEXT dropped residual branch of the backward walk is
+// mask * dres_out (hidden dropout of that branch, DropArgs br_drop; thresh 0 = no dropout) -- written here as bf16
+// (the operand format of the branch's GEMMs) together with its column sums (the branch's bias gradient, third
+// partial set), so neither a dropout/cast pass nor a column-sum pass has to re-read dres_out.
+template <int NV, typename GT, bool BR>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const GT* __restrict__ g, const float* dres_in,
                                                             float* dres_out, float* __restrict__ partial, int rows,
-                                                            int D, float eps) {
-    __shared__ float red[2][4][NV * 256];
+                                                            int D, float eps, bf16_t* __restrict__ br_out,
+                                                            DropArgs br_drop) {
+    constexpr int SETS = BR ? 3 : 2;
+    __shared__ float red[SETS][4][NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
-    f32x4 wv[NV], dw[NV], db[NV];
+    f32x4 wv[NV], dw[NV], db[NV], dbr[BR ? NV : 1];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         wv[i] = ((const f32x4*)w)[min(lane + 64 * i, nv - 1)];
 #pragma unroll
         for (int e = 0; e < 4; ++e) dw[i][e] = db[i][e] = 0.f;
+        if constexpr (BR) dbr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // the next row's x / g / dres_in are requested before the current row's four dependent wave reductions, so a wave
     // always has one row of loads in flight (the rows of a wave are 4 apart)
@@ -180,6 +187,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
         const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+        unsigned bkey = 0;
+        if constexpr (BR) bkey = drop_key(br_drop.seed, br_drop.stream, (unsigned)row);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
@@ -189,6 +198,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += rstd * (gv[i][e] * wv[i][e] - c1 - xv[i][e] * c2);
                 ((f32x4*)(dres_out + (size_t)row * D))[c] = o;
+                if constexpr (BR) {
+                    if (br_drop.thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = drop_keep(bkey, (unsigned)(4 * c + e), br_drop.thresh) ? o[e] * br_drop.scale : 0.f;
+                    }
+                    uint2 h;
+                    h.x = pack2_bf16(o[0], o[1]);
+                    h.y = pack2_bf16(o[2], o[3]);
+                    ((uint2*)(br_out + (size_t)row * D))[c] = h;
+                    // the bias gradient sums what the GEMMs will read: the bf16-rounded values
+                    dbr[i][0] += __uint_as_float(h.x << 16);
+                    dbr[i][1] += __uint_as_float(h.x & 0xffff0000u);
+                    dbr[i][2] += __uint_as_float(h.y << 16);
+                    dbr[i][3] += __uint_as_float(h.y & 0xffff0000u);
+                }
             }
         }
     }
@@ -199,21 +224,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) {
             red[0][wave][(lane + 64 * i) * 4 + e] = dw[i][e];
             red[1][wave][(lane + 64 * i) * 4 + e] = db[i][e];
+            if constexpr (BR) red[2][wave][(lane + 64 * i) * 4 + e] = dbr[i][e];
         }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
-        partial[((size_t)blockIdx.x * 2 + 0) * D + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-        partial[((size_t)blockIdx.x * 2 + 1) * D + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+#pragma unroll
+        for (int k = 0; k < SETS; ++k)
+            partial[((size_t)blockIdx.x * SETS + k) * D + c] = (red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c]);
     }
 }
 // partial[block][2][D] -> dw[D], db[D]: block = 64 columns of the 2D-wide matrix x 16 block groups
 __global__ __launch_bounds__(1024) void layernorm_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                    float* __restrict__ db, int blocks, int D) {
+                                                                    float* __restrict__ db, float* __restrict__ dbr,
+                                                                    int blocks, int D, int sets) {
     __shared__ float red[FIN_GROUPS][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;  // col in [0, 2D)
-    const float v = finish_column(partial, blocks, (size_t)2 * D, min(col, 2 * D - 1), grp, red);
-    if (grp == 0 && col < 2 * D) {
-        if (col < D) dw[col] = v; else db[col - D] = v;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;  // col in [0, sets * D)
+    const float v = finish_column(partial, blocks, (size_t)sets * D, min(col, sets * D - 1), grp, red);
+    if (grp == 0 && col < sets * D) {
+        if (col < D) dw[col] = v;
+        else if (col < 2 * D) db[col - D] = v;
+        else dbr[col - 2 * D] = v;
     }
 }
 
@@ -433,20 +463,27 @@ int launch_transpose_bf16(const void* in, void* out, int R, int C, int ldin, int
     return VITSEG_OK;
 }
 
-size_t layernorm_bwd_scratch_floats(int rows, int D) { return (size_t)((rows + 63) / 64) * 2 * D; }
+size_t layernorm_bwd_scratch_floats(int rows, int D) { return (size_t)((rows + 63) / 64) * 3 * D; }
 int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is_bf16, const float* dres_in,
                          float* dres_out, float* dw, float* db, float* scratch, int rows, int D, float eps,
-                         hipStream_t s) {
+                         hipStream_t s, void* br_out, DropArgs br_drop, float* br_dbias) {
     VITSEG_CHECK_ARG(D % 4 == 0 && D <= 1024, VITSEG_ESHAPE, "layernorm_bwd: D=%d must be a multiple of 4, <= 1024", D);
+    VITSEG_CHECK_ARG(!br_out || (g_is_bf16 && br_dbias), VITSEG_EINVAL, "layernorm_bwd: branch output needs bf16 g + dbias");
     const int blocks = (rows + 63) / 64, nvl = (D / 4 + 63) / 64;
 #define VITSEG_LNB(NV)                                                                                            \
     do {                                                                                                          \
-        if (g_is_bf16)                                                                                            \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, bf16_t>), dim3(blocks), dim3(256), 0, s, x, w,           \
-                               (const bf16_t*)g, dres_in, dres_out, scratch, rows, D, eps);                       \
+        if (br_out)                                                                                               \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, bf16_t, true>), dim3(blocks), dim3(256), 0, s, x, w,     \
+                               (const bf16_t*)g, dres_in, dres_out, scratch, rows, D, eps, (bf16_t*)br_out,       \
+                               br_drop);                                                                          \
+        else if (g_is_bf16)                                                                                       \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, bf16_t, false>), dim3(blocks), dim3(256), 0, s, x, w,    \
+                               (const bf16_t*)g, dres_in, dres_out, scratch, rows, D, eps, (bf16_t*)nullptr,      \
+                               br_drop);                                                                          \
         else                                                                                                      \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, float>), dim3(blocks), dim3(256), 0, s, x, w,            \
-                               (const float*)g, dres_in, dres_out, scratch, rows, D, eps);                        \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, float, false>), dim3(blocks), dim3(256), 0, s, x, w,     \
+                               (const float*)g, dres_in, dres_out, scratch, rows, D, eps, (bf16_t*)nullptr,       \
+                               br_drop);                                                                          \
     } while (0)
     if (nvl <= 1) VITSEG_LNB(1);
     else if (nvl <= 2) VITSEG_LNB(2);
@@ -454,7 +491,9 @@ int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is
     else VITSEG_LNB(4);
 #undef VITSEG_LNB
     VITSEG_LAUNCH_CHECK("layernorm_bwd");
-    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, s, scratch, dw, db, blocks, D);
+    const int sets = br_out ? 3 : 2;
+    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((sets * D + 63) / 64), dim3(1024), 0, s, scratch, dw, db,
+                       br_dbias, blocks, D, sets);
     VITSEG_LAUNCH_CHECK("layernorm_bwd_finish");
     return VITSEG_OK;
 }

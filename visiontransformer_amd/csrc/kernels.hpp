@@ -123,7 +123,7 @@ int launch_transpose_bf16(const void* in, void* out, int R, int C, int ldin, int
 size_t layernorm_bwd_scratch_floats(int rows, int D);
 int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is_bf16, const float* dres_in,
                          float* dres_out, float* dw, float* db, float* scratch, int rows, int D, float eps,
-                         hipStream_t s);
+                         hipStream_t s, void* br_out = nullptr, DropArgs br_drop = DropArgs{}, float* br_dbias = nullptr);
 int launch_upsample_bwd(const float* G, float* dZ, int B, int C, int g, int S, hipStream_t s);
 size_t head1x1_bwd_scratch_floats(int B, int Np, int C);
 int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* dFpre, float* dW2, float* db2,

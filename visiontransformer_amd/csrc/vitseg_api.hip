@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "profile.hpp"
 #include "plan.hpp"
 
 namespace vitseg {
@@ -66,56 +67,12 @@ Plan make_plan(const Shape& s, int B, int precision) {
     return p;
 }
 
-// ---- measurement hooks ----------------------------------------------------------
-struct ProfRec {
-    int kind;
-    double work;
-    hipEvent_t e0, e1;
-};
-struct Profiler {
-    bool on = false;
-    std::vector<ProfRec> recs;
-    std::vector<hipEvent_t> pool;
-    hipEvent_t get() {
-        if (!pool.empty()) {
-            hipEvent_t e = pool.back();
-            pool.pop_back();
-            return e;
-        }
-        hipEvent_t e = nullptr;
-        (void)hipEventCreate(&e);
-        return e;
-    }
-    void clear() {
-        for (auto& r : recs) {
-            pool.push_back(r.e0);
-            pool.push_back(r.e1);
-        }
-        recs.clear();
-    }
-};
-Profiler g_prof;
-
-struct ProfScope {  // brackets the launches issued during its lifetime
-    hipStream_t st;
-    bool active;
-    ProfRec r;
-    ProfScope(int kind, double work, hipStream_t s) : st(s), active(g_prof.on) {
-        if (!active) return;
-        r.kind = kind;
-        r.work = work;
-        r.e0 = g_prof.get();
-        r.e1 = g_prof.get();
-        (void)hipEventRecord(r.e0, st);
-    }
-    ~ProfScope() {
-        if (!active) return;
-        (void)hipEventRecord(r.e1, st);
-        g_prof.recs.push_back(r);
-    }
-};
-
 }  // namespace
+
+Profiler& profiler() {
+    static Profiler p;
+    return p;
+}
 }  // namespace vitseg
 
 using namespace vitseg;
@@ -318,8 +275,8 @@ int vitseg_ce_loss(const float* lowres, const void* target, int target_is_u8, fl
 }
 
 int vitseg_profile_enable(int on) {
-    g_prof.clear();
-    g_prof.on = on != 0;
+    profiler().clear();
+    profiler().on = on != 0;
     return VITSEG_OK;
 }
 
@@ -327,7 +284,7 @@ int vitseg_profile_collect(int kind, double* total_ms, int64_t* launches, double
     VITSEG_CHECK_ARG(kind >= 0 && kind < VITSEG_K_COUNT, VITSEG_EINVAL, "kernel kind %d", kind);
     double ms = 0, w = 0;
     int64_t n = 0;
-    for (auto& r : g_prof.recs) {
+    for (auto& r : profiler().recs) {
         if (r.kind != kind) continue;
         hipError_t e = hipEventSynchronize(r.e1);
         if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");

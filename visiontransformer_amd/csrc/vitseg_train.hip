@@ -4,6 +4,7 @@
 // applied (p = 0): train-mode bitwise parity with torch's RNG stream is impossible anyway
 //  and the parity tests run with dropout off.
 #include "kernels.hpp"
+#include "profile.hpp"
 #include "plan.hpp"
 
 using namespace vitseg;
@@ -185,6 +186,14 @@ GemmArgs lin(const void* A, const void* W, const float* bias, const float* R, vo
 }
 
 
+// algorithmic FLOPs of one layer's attention; products_x2 = 2 x the number of distinct N x N x hd matrix products:
+// 4 for the forward (S, PV), 10 for the backward (S, dP, dV, dK, dQ -- the second kernel's recomputation of S and dP
+// is not algorithmic work and is not counted)
+static double attn_flops(const Ctx& c, int products_x2) {
+    const double N = c.s.Np + 1;
+    return (double)products_x2 * c.B * c.s.A * N * N * (c.s.D / c.s.A);
+}
+
 // =========================================================================================================
 // Mixed-precision (bf16 operands, fp32 master weights / residual stream / gradients) training path.
 // dgrad = N-form bf16 GEMM against a transposed bf16 copy of the (small) weight; wgrad = the T-form/T-form
@@ -216,15 +225,25 @@ int forward_train_bf16(Ctx& c, const float* x, float* logits) {
             g.thin_scratch = c.T(c.p.wscratch);
             g.thin_capacity = c.p.wscratch_floats;
         }
-        if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_BIAS, st))) return rc;
-        if ((rc = launch_attention_bf16(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, c.dr(l, 1), st))) return rc;
+        {
+            ProfScope ps(VITSEG_K_TRAIN_GEMM_FWD, 2.0 * Mt * 3 * D * D, st);
+            if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_BIAS, st))) return rc;
+        }
+        {
+            ProfScope ps(VITSEG_K_TRAIN_ATTN_FWD, attn_flops(c, 4), st);
+            if ((rc = launch_attention_bf16(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, c.dr(l, 1), st))) return rc;
+        }
         g = lin(CTX, c.WL(VITSEG_T_WO, l), c.W(VITSEG_T_BO, l), Xin, Xmid, Mt, D, D, D, D);
         g.drop = c.dr(l, 2);
-        if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_RESADD, st))) return rc;
+        {
+            ProfScope ps(VITSEG_K_TRAIN_GEMM_FWD, 2.0 * Mt * D * D, st);
+            if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_RESADD, st))) return rc;
+        }
         if ((rc = launch_layernorm(Xmid, c.W(VITSEG_T_LN2_W, l), c.W(VITSEG_T_LN2_B, l), H2, Mt, D, c.eps, true, st)))
             return rc;
         g = lin(H2, c.WL(VITSEG_T_W1, l), c.W(VITSEG_T_B1, l), nullptr, c.LV(l, c.p.lb.uact), Mt, I, D, D, I);
         g.aux = c.LV(l, c.p.lb.upre);
+        ProfScope ps(VITSEG_K_TRAIN_GEMM_FWD, 4.0 * Mt * D * I, st);
         if ((rc = launch_gemm_bf16_train(g, EPI_GELU, 0, nullptr, st))) return rc;
         g = lin(c.LV(l, c.p.lb.uact), c.WL(VITSEG_T_W2, l), c.W(VITSEG_T_B2, l), Xmid, Xout, Mt, D, I, I, D);
         g.drop = c.dr(l, 3);
@@ -267,12 +286,14 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
         GemmArgs g = lin(dY, X, nullptr, nullptr, dW, Nd, Kd, Mt, Nd, Kd);  // both operands T-form, no copies
         g.ldw = Kd;
         g.zeros = c.ws + c.p.zero;
+        ProfScope ps(VITSEG_K_TRAIN_WGRAD, 2.0 * Mt * Nd * Kd, st);
         return launch_wgrad_bf16_tt(g, wscr, st);
     };
     (void)Kpad;
     // dX[Mt,Kd] = dY[Mt,Nd] . W[Nd,Kd]  with W^T materialised as [Kd][Nd] bf16
     auto dgrad = [&](const void* dY, const unsigned short* Wlp, void* dX, int Nd, int Kd, int epi, const void* R) {
         int r;
+        ProfScope ps(VITSEG_K_TRAIN_DGRAD, 2.0 * Mt * Nd * Kd, st);
         if ((r = launch_transpose_bf16(Wlp, wT, Nd, Kd, Kd, Nd, st))) return r;
         GemmArgs g = lin(dY, wT, nullptr, (const float*)R, dX, Mt, Kd, Nd, Nd, Kd);
         g.ldw = Nd;
@@ -333,12 +354,16 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
     // ---- 4. encoder layers ----
     void *dH = c.TV(c.p.dh), *dU = c.TV(c.p.du), *dQKV = c.TV(c.p.dqkv), *dCTX = c.TV(c.p.dctx);
     for (int l = s.L - 1; l >= 0; --l) {
-        if (c.drop_p > 0.f) {  // gradient entering the dropped branch: mask fused into the bf16 cast
-            if ((rc = launch_dropout_rows(dXa, dXc, 1, Mt, D, c.dr(l, 3), st))) return rc;
+        // The gradient entering a dropped residual branch (bf16, hidden-dropout mask applied) and the branch's bias
+        // gradient are by-products of the LayerNorm backward that produced the residual-stream gradient (BR outputs);
+        // only the first one of the walk, fed by the final norm (patch rows only), is a pass of its own.
+        if (l == s.L - 1) {
+            if (c.drop_p > 0.f) {
+                if ((rc = launch_dropout_rows(dXa, dXc, 1, Mt, D, c.dr(l, 3), st))) return rc;
+            } else {
+                if ((rc = launch_cast_bf16(dXa, dXc, (size_t)Mt * D, st))) return rc;
+            }
             if ((rc = launch_colsum(dXc, 1, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
-        } else {
-            if ((rc = launch_cast_bf16(dXa, dXc, (size_t)Mt * D, st))) return rc;
-            if ((rc = launch_colsum(dXa, 0, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
         }
         if ((rc = wgrad(dXc, c.LV(l, c.p.lb.uact), G(VITSEG_T_W2, l), D, I))) return rc;
         if ((rc = dgrad(dXc, c.WL(VITSEG_T_W2, l), dU, D, I, EPI_DGELU, c.LV(l, c.p.lb.upre)))) return rc;
@@ -346,26 +371,28 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
         if ((rc = wgrad(dU, c.LV(l, c.p.lb.h2), G(VITSEG_T_W1, l), I, D))) return rc;
         if ((rc = dgrad(dU, c.WL(VITSEG_T_W1, l), dH, I, D, EPI_BIAS, nullptr))) return rc;
         if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xmid), c.W(VITSEG_T_LN2_W, l), dH, 1, dXa, dXb, G(VITSEG_T_LN2_W, l),
-                                       G(VITSEG_T_LN2_B, l), scratch, Mt, D, c.eps, st)))
+                                       G(VITSEG_T_LN2_B, l), scratch, Mt, D, c.eps, st, dXc, c.dr(l, 2), G(VITSEG_T_BO, l))))
             return rc;
-        if (c.drop_p > 0.f) {
-            if ((rc = launch_dropout_rows(dXb, dXc, 1, Mt, D, c.dr(l, 2), st))) return rc;
-            if ((rc = launch_colsum(dXc, 1, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
-        } else {
-            if ((rc = launch_cast_bf16(dXb, dXc, (size_t)Mt * D, st))) return rc;
-            if ((rc = launch_colsum(dXb, 0, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
-        }
         if ((rc = wgrad(dXc, c.LV(l, c.p.lb.ctx), G(VITSEG_T_WO, l), D, D))) return rc;
         if ((rc = dgrad(dXc, c.WL(VITSEG_T_WO, l), dCTX, D, D, EPI_BIAS, nullptr))) return rc;
-        if ((rc = launch_attention_bwd_bf16(c.LV(l, c.p.lb.qkv), c.LV(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
-                                            c.T(c.p.dvec), dQKV, B, s.Np, s.A, c.dr(l, 1), st)))
-            return rc;
+        {
+            ProfScope ps(VITSEG_K_TRAIN_ATTN_BWD, attn_flops(c, 10), st);
+            if ((rc = launch_attention_bwd_bf16(c.LV(l, c.p.lb.qkv), c.LV(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
+                                                c.T(c.p.dvec), dQKV, B, s.Np, s.A, c.dr(l, 1), st)))
+                return rc;
+        }
         if ((rc = launch_colsum(dQKV, 1, G(VITSEG_T_BQKV, l), scratch, Mt, 3 * D, 3 * D, st))) return rc;
         if ((rc = wgrad(dQKV, c.LV(l, c.p.lb.h1), G(VITSEG_T_WQKV, l), 3 * D, D))) return rc;
         if ((rc = dgrad(dQKV, c.WL(VITSEG_T_WQKV, l), dH, 3 * D, D, EPI_BIAS, nullptr))) return rc;
-        if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xin), c.W(VITSEG_T_LN1_W, l), dH, 1, dXb, dXa, G(VITSEG_T_LN1_W, l),
-                                       G(VITSEG_T_LN1_B, l), scratch, Mt, D, c.eps, st)))
+        if (l > 0) {  // next branch of the walk: layer l-1's MLP output
+            if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xin), c.W(VITSEG_T_LN1_W, l), dH, 1, dXb, dXa, G(VITSEG_T_LN1_W, l),
+                                           G(VITSEG_T_LN1_B, l), scratch, Mt, D, c.eps, st, dXc, c.dr(l - 1, 3),
+                                           G(VITSEG_T_B2, l - 1))))
+                return rc;
+        } else if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xin), c.W(VITSEG_T_LN1_W, l), dH, 1, dXb, dXa,
+                                              G(VITSEG_T_LN1_W, l), G(VITSEG_T_LN1_B, l), scratch, Mt, D, c.eps, st))) {
             return rc;
+        }
         if ((rc = c.mark(s.L - l))) return rc;  // bucket 1 + (L-1-l): layer l
     }
     // ---- 5. embeddings (fp32) ----
@@ -438,15 +465,25 @@ int vitseg_forward_train(const vitseg_config* cfg, const float* params, const vo
         if ((rc = launch_layernorm(Xin, c.W(VITSEG_T_LN1_W, l), c.W(VITSEG_T_LN1_B, l), H1, Mt, D, c.eps, false, st)))
             return rc;
         GemmArgs g = lin(H1, c.W(VITSEG_T_WQKV, l), c.W(VITSEG_T_BQKV, l), nullptr, QKV, Mt, 3 * D, D, D, 3 * D);
-        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_BIAS, st))) return rc;
-        if ((rc = launch_attention_f32(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, c.dr(l, 1), st))) return rc;
+        {
+            ProfScope ps(VITSEG_K_TRAIN_GEMM_FWD, 2.0 * Mt * 3 * D * D, st);
+            if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_BIAS, st))) return rc;
+        }
+        {
+            ProfScope ps(VITSEG_K_TRAIN_ATTN_FWD, attn_flops(c, 4), st);
+            if ((rc = launch_attention_f32(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, c.dr(l, 1), st))) return rc;
+        }
         g = lin(CTX, c.W(VITSEG_T_WO, l), c.W(VITSEG_T_BO, l), Xin, Xmid, Mt, D, D, D, D);
         g.drop = c.dr(l, 2);
-        if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_RESADD, st))) return rc;
+        {
+            ProfScope ps(VITSEG_K_TRAIN_GEMM_FWD, 2.0 * Mt * D * D, st);
+            if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_RESADD, st))) return rc;
+        }
         if ((rc = launch_layernorm(Xmid, c.W(VITSEG_T_LN2_W, l), c.W(VITSEG_T_LN2_B, l), H2, Mt, D, c.eps, false, st)))
             return rc;
         g = lin(H2, c.W(VITSEG_T_W1, l), c.W(VITSEG_T_B1, l), nullptr, c.L(l, c.p.lb.uact), Mt, I, D, D, I);
         g.aux = c.L(l, c.p.lb.upre);
+        ProfScope ps(VITSEG_K_TRAIN_GEMM_FWD, 4.0 * Mt * D * I, st);
         if ((rc = launch_gemm_f32(g, A_PLAIN, EPI_GELU, st))) return rc;
         g = lin(c.L(l, c.p.lb.uact), c.W(VITSEG_T_W2, l), c.W(VITSEG_T_B2, l), Xmid, Xout, Mt, D, I, I, D);
         g.drop = c.dr(l, 3);
@@ -499,12 +536,14 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const void* p
     auto dgrad = [&](const float* dY, const float* Wt, float* dX, int M, int Nd, int Kd, int epi, const float* R) {
         GemmArgs g = lin(dY, Wt, nullptr, R, dX, M, Kd, Nd, Nd, Kd);
         g.ldw = Kd;
+        ProfScope ps(VITSEG_K_TRAIN_DGRAD, 2.0 * M * Nd * Kd, st);
         return launch_gemm_f32_bwd(g, A_PLAIN, 0, 1, epi, st);
     };
     // wgrad: dW[Nd,Kd] = dY[M,Nd]^T . X[M,Kd]   (both T-form, reduction over the M token rows)
     auto wgrad = [&](const float* dY, const float* X, float* dW, int M, int Nd, int Kd) {
         GemmArgs g = lin(dY, X, nullptr, nullptr, dW, Nd, Kd, M, Nd, Kd);
         g.ldw = Kd;
+        ProfScope ps(VITSEG_K_TRAIN_WGRAD, 2.0 * M * Nd * Kd, st);
         return launch_wgrad_f32(g, c.T(c.p.wscratch), st);
     };
 
@@ -576,9 +615,12 @@ int vitseg_backward(const vitseg_config* cfg, const float* params, const void* p
         if ((rc = launch_colsum(dB, 0, G(VITSEG_T_BO, l), scratch, Mt, D, D, st))) return rc;
         if ((rc = wgrad(dB, c.L(l, c.p.lb.ctx), G(VITSEG_T_WO, l), Mt, D, D))) return rc;
         if ((rc = dgrad(dB, c.W(VITSEG_T_WO, l), dCTX, Mt, D, D, EPI_BIAS, nullptr))) return rc;
-        if ((rc = launch_attention_bwd_f32(c.L(l, c.p.lb.qkv), c.L(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
-                                           c.T(c.p.dvec), dQKV, B, s.Np, s.A, c.dr(l, 1), st)))
-            return rc;
+        {
+            ProfScope ps(VITSEG_K_TRAIN_ATTN_BWD, attn_flops(c, 10), st);
+            if ((rc = launch_attention_bwd_f32(c.L(l, c.p.lb.qkv), c.L(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
+                                               c.T(c.p.dvec), dQKV, B, s.Np, s.A, c.dr(l, 1), st)))
+                return rc;
+        }
         if ((rc = launch_colsum(dQKV, 0, G(VITSEG_T_BQKV, l), scratch, Mt, 3 * D, 3 * D, st))) return rc;
         if ((rc = wgrad(dQKV, c.L(l, c.p.lb.h1), G(VITSEG_T_WQKV, l), Mt, 3 * D, D))) return rc;
         if ((rc = dgrad(dQKV, c.W(VITSEG_T_WQKV, l), dH, Mt, 3 * D, D, EPI_BIAS, nullptr))) return rc;
