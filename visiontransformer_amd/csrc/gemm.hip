@@ -595,11 +595,14 @@ int launch_one(GemmArgs a, hipStream_t s) {
 
 namespace {
 
-// out[r][c4] = epi(sum_s partial[s][r][c4] + bias): the K slices of the CLS rows, summed in slice order (deterministic)
+// out[r][c4] = epi(sum_s partial[s][r][c4] + bias): the K slices of the CLS rows, summed in slice order (deterministic).
+// The epilogue is the tile kernels' one, including the training forms: hidden dropout on the residual branch (RESADD),
+// the saved GELU derivative (GELU with aux, 16-bit) and the multiplication by it (DGELU, R = 16-bit derivative rows).
 template <int EPI, typename OutT>
 __global__ __launch_bounds__(256) void thin_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                                           const float* __restrict__ R, OutT* __restrict__ C, int rows, int N,
-                                                          int ldc, int splits) {
+                                                          int ldc, int splits, OutT* __restrict__ aux, DropArgs drop,
+                                                          unsigned row0) {
     const int n4 = N >> 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * n4) return;
@@ -615,11 +618,27 @@ __global__ __launch_bounds__(256) void thin_reduce_kernel(const float* __restric
     if (bias) b4 = *(const f32x4*)(bias + c);
     f32x4 res = {0.f, 0.f, 0.f, 0.f};
     if (EPI == EPI_RESADD) res = *(const f32x4*)(R + (size_t)r * ldc + c);
+    if constexpr (EPI == EPI_DGELU) {
+        const uint2 d = *(const uint2*)((const OutT*)R + (size_t)r * ldc + c);
+        res[0] = H16<OutT>::lo(d.x);
+        res[1] = H16<OutT>::hi(d.x);
+        res[2] = H16<OutT>::lo(d.y);
+        res[3] = H16<OutT>::hi(d.y);
+    }
+    f32x4 der = {0.f, 0.f, 0.f, 0.f};
+    const unsigned key = drop.thresh ? drop_key(drop.seed, drop.stream, row0 + (unsigned)r) : 0u;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float x = acc[e] + b4[e];
-        if (EPI == EPI_GELU) x = sizeof(OutT) == 4 ? gelu_erf(x) : gelu_erf_fast(x);  // as the tile kernels of that format
-        if (EPI == EPI_RESADD) x = res[e] + x;
+        if (EPI == EPI_GELU) {
+            if (sizeof(OutT) != 4 && aux) der[e] = gelu_erf_grad_fast(x);
+            x = sizeof(OutT) == 4 ? gelu_erf(x) : gelu_erf_fast(x);  // as the tile kernels of that format
+        }
+        if (EPI == EPI_RESADD) {
+            if (drop.thresh) x = drop_keep(key, (unsigned)(c + e), drop.thresh) ? x * drop.scale : 0.f;
+            x = res[e] + x;
+        }
+        if (EPI == EPI_DGELU) x *= res[e];
         acc[e] = x;
     }
     if constexpr (sizeof(OutT) == 4) {
@@ -629,6 +648,11 @@ __global__ __launch_bounds__(256) void thin_reduce_kernel(const float* __restric
         h.x = H16<OutT>::pack2(acc[0], acc[1]);
         h.y = H16<OutT>::pack2(acc[2], acc[3]);
         *(uint2*)(C + (size_t)r * ldc + c) = h;
+        if (EPI == EPI_GELU && aux) {
+            h.x = H16<OutT>::pack2(der[0], der[1]);
+            h.y = H16<OutT>::pack2(der[2], der[3]);
+            *(uint2*)(aux + (size_t)r * ldc + c) = h;
+        }
     }
 }
 
@@ -636,21 +660,28 @@ template <typename OutT>
 int launch_thin_reduce(const GemmArgs& a, int epi, int splits, hipStream_t s) {
     const int rows = a.thin_rows, body = a.M - rows;
     const int blocks = (rows * (a.N / 4) + 255) / 256;
-    const float* R = a.R ? a.R + (size_t)body * a.ldc : nullptr;
+    const float* R = nullptr;
+    if (a.R) R = epi == EPI_DGELU ? (const float*)((const OutT*)a.R + (size_t)body * a.ldc) : a.R + (size_t)body * a.ldc;
     OutT* C = (OutT*)a.C + (size_t)body * a.ldc;
+    OutT* aux = a.aux ? (OutT*)a.aux + (size_t)body * a.ldc : nullptr;
+    const unsigned row0 = (unsigned)(a.row_base + body);
+#define VITSEG_THIN(E)                                                                                                 \
+    hipLaunchKernelGGL((thin_reduce_kernel<E, OutT>), dim3(blocks), dim3(256), 0, s, a.thin_scratch, a.bias, R, C, rows, \
+                       a.N, a.ldc, splits, aux, a.drop, row0)
     switch (epi) {
-        case EPI_BIAS:
-            hipLaunchKernelGGL((thin_reduce_kernel<EPI_BIAS, OutT>), dim3(blocks), dim3(256), 0, s, a.thin_scratch, a.bias, R, C,
-                               rows, a.N, a.ldc, splits);
+        case EPI_BIAS: VITSEG_THIN(EPI_BIAS); break;
+        case EPI_GELU: VITSEG_THIN(EPI_GELU); break;
+        case EPI_DGELU:
+            if constexpr (sizeof(OutT) == 4) {
+                set_error("thin_reduce: dGELU epilogue is 16-bit only");
+                return VITSEG_EINVAL;
+            } else {
+                VITSEG_THIN(EPI_DGELU);
+            }
             break;
-        case EPI_GELU:
-            hipLaunchKernelGGL((thin_reduce_kernel<EPI_GELU, OutT>), dim3(blocks), dim3(256), 0, s, a.thin_scratch, a.bias, R, C,
-                               rows, a.N, a.ldc, splits);
-            break;
-        default:
-            hipLaunchKernelGGL((thin_reduce_kernel<EPI_RESADD, OutT>), dim3(blocks), dim3(256), 0, s, a.thin_scratch, a.bias, R,
-                               C, rows, a.N, a.ldc, splits);
+        default: VITSEG_THIN(EPI_RESADD);
     }
+#undef VITSEG_THIN
     VITSEG_LAUNCH_CHECK("thin_reduce");
     return VITSEG_OK;
 }
@@ -664,10 +695,12 @@ int whole_split_applies(const GemmArgs& a, int epi, int kstep) {
     return ok ? sp : 0;
 }
 
-bool thin_split_applies(const GemmArgs& a, int epi) {
+// h16: the 16-bit path's reducing epilogue also covers dropout, the saved GELU derivative and dGELU (training)
+bool thin_split_applies(const GemmArgs& a, int epi, bool h16 = false) {
     return a.thin_scratch && a.thin_rows > 0 && a.thin_rows <= THIN_MAX_ROWS && a.M > a.thin_rows &&
-           (a.M - a.thin_rows) % BM == 0 && a.K >= 256 && a.K % 32 == 0 && !a.drop.thresh && !a.aux && a.splitk <= 1 &&
-           a.ldc % 4 == 0 && (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESADD);
+           (a.M - a.thin_rows) % BM == 0 && a.K >= 256 && a.K % 32 == 0 && (h16 || (!a.drop.thresh && !a.aux)) &&
+           a.splitk <= 1 && a.ldc % 4 == 0 &&
+           (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESADD || (h16 && epi == EPI_DGELU));
 }
 
 template <int X3>
@@ -710,6 +743,8 @@ int launch_thin_rows_h16(const GemmArgs& a, int epi, hipStream_t s, int splits =
     t.splitk = splits;
     t.split_stride = (size_t)rows * a.N;
     t.thin_scratch = nullptr;
+    t.aux = nullptr;      // the training epilogues run in the reducing kernel
+    t.drop = DropArgs{};
     if (int rc = launch_one<T, float, A_PLAIN, EPI_BIAS>(t, s)) return rc;
     return epi == EPI_RESADD ? launch_thin_reduce<float>(a, epi, splits, s) : launch_thin_reduce<T>(a, epi, splits, s);
 }
@@ -1162,7 +1197,7 @@ int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
             return launch_thin_rows_h16<T>(w, epi, s, sp);
         }
     }
-    if (amode == A_PLAIN && thin_split_applies(a_in, epi) && (a_in.M - a_in.thin_rows) % LBM == 0 && a_in.K % 64 == 0) {
+    if (amode == A_PLAIN && thin_split_applies(a_in, epi, true) && (a_in.M - a_in.thin_rows) % LBM == 0 && a_in.K % 64 == 0) {
         if (int rc = launch_thin_rows_h16<T>(a_in, epi, s)) return rc;  // CLS rows: split-K side launch (GemmArgs)
         a.M = a_in.M - a_in.thin_rows;
     }

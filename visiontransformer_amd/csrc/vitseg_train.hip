@@ -219,12 +219,16 @@ int forward_train_bf16(Ctx& c, const float* x, float* logits) {
         void *H1 = c.LV(l, c.p.lb.h1), *QKV = c.LV(l, c.p.lb.qkv), *CTX = c.LV(l, c.p.lb.ctx), *H2 = c.LV(l, c.p.lb.h2);
         if ((rc = launch_layernorm(Xin, c.W(VITSEG_T_LN1_W, l), c.W(VITSEG_T_LN1_B, l), H1, Mt, D, c.eps, true, st)))
             return rc;
+        // CLS rows as a split-K side launch with the same epilogue (whole-tile body, see GemmArgs::thin_rows)
+        auto thin = [&](GemmArgs& t) {
+            if (Mp % 256 == 0 && batch <= THIN_MAX_ROWS) {
+                t.thin_rows = batch;
+                t.thin_scratch = c.T(c.p.wscratch);
+                t.thin_capacity = c.p.wscratch_floats;
+            }
+        };
         GemmArgs g = lin(H1, c.WL(VITSEG_T_WQKV, l), c.W(VITSEG_T_BQKV, l), nullptr, QKV, Mt, 3 * D, D, D, 3 * D);
-        if (Mp % 256 == 0 && batch <= THIN_MAX_ROWS) {
-            g.thin_rows = batch;
-            g.thin_scratch = c.T(c.p.wscratch);
-            g.thin_capacity = c.p.wscratch_floats;
-        }
+        thin(g);
         {
             ProfScope ps(VITSEG_K_TRAIN_GEMM_FWD, 2.0 * Mt * 3 * D * D, st);
             if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_BIAS, st))) return rc;
@@ -235,6 +239,7 @@ int forward_train_bf16(Ctx& c, const float* x, float* logits) {
         }
         g = lin(CTX, c.WL(VITSEG_T_WO, l), c.W(VITSEG_T_BO, l), Xin, Xmid, Mt, D, D, D, D);
         g.drop = c.dr(l, 2);
+        thin(g);
         {
             ProfScope ps(VITSEG_K_TRAIN_GEMM_FWD, 2.0 * Mt * D * D, st);
             if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_RESADD, st))) return rc;
@@ -243,10 +248,12 @@ int forward_train_bf16(Ctx& c, const float* x, float* logits) {
             return rc;
         g = lin(H2, c.WL(VITSEG_T_W1, l), c.W(VITSEG_T_B1, l), nullptr, c.LV(l, c.p.lb.uact), Mt, I, D, D, I);
         g.aux = c.LV(l, c.p.lb.upre);
+        thin(g);
         ProfScope ps(VITSEG_K_TRAIN_GEMM_FWD, 4.0 * Mt * D * I, st);
         if ((rc = launch_gemm_bf16_train(g, EPI_GELU, 0, nullptr, st))) return rc;
         g = lin(c.LV(l, c.p.lb.uact), c.WL(VITSEG_T_W2, l), c.W(VITSEG_T_B2, l), Xmid, Xout, Mt, D, I, I, D);
         g.drop = c.dr(l, 3);
+        thin(g);
         if ((rc = launch_gemm_bf16(g, A_PLAIN, EPI_RESADD, st))) return rc;
     }
     void* Hf = c.TV(c.p.hf);
