@@ -467,12 +467,17 @@ def test_training_step_vitb_width_512_dropout_masks_injected(precision):
 
 
 @pytest.mark.parametrize("B,Np,A,p", [(2, 256, 2, 0.0), (1, 1024, 2, 0.0), (2, 196, 3, 0.0), (1, 64, 1, 0.0), (2, 100, 2, 0.0),
-                                      (1, 1024, 1, 0.1), (2, 196, 2, 0.1), (2, 256, 3, 0.1)])
+                                      (1, 1024, 1, 0.1), (2, 196, 2, 0.1), (2, 256, 3, 0.1),
+                                      (1, 1024, 1, -0.1), (2, 256, 3, -0.1)])
 def test_attention_backward_bf16(B, Np, A, p):
     """bf16 attention core, forward (ctx, log-sum-exp) + backward (dq | dk | dv), with and without the attention-probability
     dropout (the kernels' counter-based mask regenerated in numpy and injected into the reference), against fp64 autograd
-    on the same bf16-rounded inputs.  Whole-tile (Np % 128 == 0) and ragged shapes; the CLS token takes the vector paths."""
+    on the same bf16-rounded inputs.  Whole-tile (Np % 128 == 0) and ragged shapes; the CLS token takes the vector paths.
+    p < 0: |p| with the keep bits precomputed as mask words (attention_dropmask.hip, the training step's path) -- the same
+    reference masks, so this also pins the word layout against tests/dropout_ref.py."""
     from dropout_ref import Masks
+    words = p < 0
+    p = abs(p)
     D, Mt, N = 64 * A, B * Np + B, Np + 1
     qkv = _rand(Mt, 3 * D, seed=Np + A, scale=1.2).to(torch.bfloat16)
     dctx = _rand(Mt, D, seed=9).to(torch.bfloat16)
@@ -499,9 +504,10 @@ def test_attention_backward_bf16(B, Np, A, p):
     lse = torch.empty(B * A * N, device=DEV)
     scr = torch.empty(B * A * N, device=DEV)
     dqkv = torch.full((Mt, 3 * D), float("nan"), device=DEV, dtype=torch.bfloat16)
+    mw = torch.empty(_lib.lib().vitseg_attention_dropmask_bytes(B, Np, A), dtype=torch.uint8, device=DEV) if words else None
     _lib.check(_lib.lib().vitseg_op_attention_bwd_bf16(qd.data_ptr(), dd.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
                                                        scr.data_ptr(), dqkv.data_ptr(), B, Np, A, p, seed, stream_id,
-                                                       _stream()))
+                                                       mw.data_ptr() if words else None, _stream()))
     got, ref = dqkv.float().cpu().double(), x.grad
     assert torch.isfinite(got).all()
     assert (ctx.float().cpu().double() - ctx_ref).abs().max().item() < 4e-2

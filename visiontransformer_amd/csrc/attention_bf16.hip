@@ -36,11 +36,15 @@ __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 
 // in the 16-bit P.  (Prescaling q by c instead would save the multiply too, but a second rounding of q to the 16-bit
 // format costs accuracy on peaked rows: measured 0.041 vs 0.03 max error in the op test; it belongs into the QKV
 // projection's epilogue, before the first rounding.)
+// MW (with DROP, without RAGGED): the keep bits come as precomputed words (common.hpp attn_dropmask_words): the lane mask
+// of accumulator register r is one scalar 64-bit load, applied with one v_cndmask; the 1 / (1 - p) factor moves into the
+// final normalisation.
 constexpr float DEFER_THR = 8.0f;
-template <bool DROP, bool RAGGED, typename H>
+template <bool DROP, bool RAGGED, bool MW, typename H>
 __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ lse, int B, int Np, int A,
-                                                           DropArgs dr) {
+                                                           DropArgs dr, const unsigned* __restrict__ maskw) {
+    static_assert(!MW || (DROP && !RAGGED), "mask words: dropout on, whole 128-query blocks");
     // [buffer][K|V][key * 64 + d] bf16, rows of 128 B with XOR-swizzled 16-B chunks: 32 KiB
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][KB * HD];
 
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
                 o[dt][4 * g4 + 3] = H16<H>::hi(t.y);
             }
         if (DROP) {
-            const float kc = drop_keep(dkey, (unsigned)Np, dr.thresh) ? dr.scale : 0.f;
+            const float kc = drop_keep(dkey, (unsigned)Np, dr.thresh) ? (MW ? 1.f : dr.scale) : 0.f;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -133,11 +137,20 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
     const int v_dchunk = 2 * (grp & 1) + (tp >> 1), v_half = (tp & 1) * 4;
 
     const int nkt = (Np + KB - 1) / KB;
+    // this wave's row of mask words: 16 lane masks (64-bit) per 32-key block, wave-uniform address -> scalar loads
+    const unsigned long* mrow = nullptr;
+    if (MW) {
+        const int nb = Np >> 5, qg = at.rt * 4 + __builtin_amdgcn_readfirstlane(wave);
+        mrow = (const unsigned long*)maskw + ((size_t)((b * A + head) * nb + qg) * nb) * 16;
+    }
+    TileMasks lm;
+    if (MW) lm.load(mrow);
     gload(0);
     swrite(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
+        if (MW) lm.wait();
         gload(min(kt + 1, nkt - 1));  // the last tile re-stages itself: keeps the body branch-free
         const bf16_t* Ks = lds[buf][0];
         const bf16_t* Vs = lds[buf][1];
@@ -190,7 +203,10 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
                 float p0 = __builtin_amdgcn_exp2f(st[kb][r] * c);
                 float p1 = __builtin_amdgcn_exp2f(st[kb][r + 1] * c);
                 psum += p0 + p1;
-                if (DROP) {
+                if (MW) {
+                    p0 = mask_select(lm.reg(kb, r), p0);
+                    p1 = mask_select(lm.reg(kb, r + 1), p1);
+                } else if (DROP) {
                     const unsigned k0 = (unsigned)(kt * KB + kb * 32);
                     p0 = drop_keep(dkey, k0 + kappa(r, lh), dr.thresh) ? p0 * dr.scale : 0.f;
                     p1 = drop_keep(dkey, k0 + kappa(r + 1, lh), dr.thresh) ? p1 * dr.scale : 0.f;
@@ -219,13 +235,14 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
                 }
             }
 
+        if (MW) lm.load(mrow + (size_t)min(kt + 1, nkt - 1) * 32);   // next tile's lane masks (see TileMasks)
         swrite(buf ^ 1);
         __syncthreads();
     }
 
     // ---- normalise and store: lane holds d = 32 dt + 8 g4 + 4 lh + e of its query ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    const float inv = (MW ? dr.scale : 1.0f) / l_tot;
     // log-sum-exp of the scaled scores in log2 units, [b][head][token] with the CLS token last (backward)
     if (lse && q_valid && lh == 0)
         lse[((size_t)b * A + head) * (Np + 1) + q_local] = m_run * c + __builtin_amdgcn_logf(l_tot);
@@ -346,16 +363,20 @@ __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __res
 }  // namespace
 
 template <typename H>
-static int launch_attention_h16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s) {
+static int launch_attention_h16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s,
+                                const unsigned* maskw) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_bf16: bad arguments");
     const dim3 grid((unsigned)((Np + QB - 1) / QB) * A * B);  // 1-D: attn_tile() places the tiles
     const bool ragged = Np % QB != 0, drop = dr.thresh != 0;
-#define VITSEG_ATTN_LAUNCH(DR, RG)                                                                                       \
-    hipLaunchKernelGGL((attn_bf16_kernel<DR, RG, H>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse, B, Np, A, dr)
+#define VITSEG_ATTN_LAUNCH(DR, RG, MWORDS)                                                                           \
+    hipLaunchKernelGGL((attn_bf16_kernel<DR, RG, MWORDS, H>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, \
+                       lse, B, Np, A, dr, maskw)
     if (drop) {
-        if (ragged) VITSEG_ATTN_LAUNCH(true, true); else VITSEG_ATTN_LAUNCH(true, false);
+        if (ragged) VITSEG_ATTN_LAUNCH(true, true, false);
+        else if (maskw) VITSEG_ATTN_LAUNCH(true, false, true);
+        else VITSEG_ATTN_LAUNCH(true, false, false);
     } else {
-        if (ragged) VITSEG_ATTN_LAUNCH(false, true); else VITSEG_ATTN_LAUNCH(false, false);
+        if (ragged) VITSEG_ATTN_LAUNCH(false, true, false); else VITSEG_ATTN_LAUNCH(false, false, false);
     }
 #undef VITSEG_ATTN_LAUNCH
     VITSEG_LAUNCH_CHECK("attn_bf16");
@@ -368,9 +389,9 @@ static int launch_attention_h16(const void* qkv, void* ctx, float* lse, int B, i
 }
 
 int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s,
-                          bool f16) {
-    return f16 ? launch_attention_h16<f16_t>(qkv, ctx, lse, B, Np, A, dr, s)
-               : launch_attention_h16<bf16_t>(qkv, ctx, lse, B, Np, A, dr, s);
+                          bool f16, const unsigned* maskw) {
+    return f16 ? launch_attention_h16<f16_t>(qkv, ctx, lse, B, Np, A, dr, s, maskw)
+               : launch_attention_h16<bf16_t>(qkv, ctx, lse, B, Np, A, dr, s, maskw);
 }
 
 }  // namespace vitseg

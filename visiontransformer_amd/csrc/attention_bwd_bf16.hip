@@ -104,13 +104,16 @@ __device__ __forceinline__ float dot_frag(const f32x4 (&a)[4], const f32x4 (&b)[
 }
 
 // ---------------------------------------------------------------------------------- dQ (patch queries)
-template <bool DROP, bool RAGGED>
+// MW (both MFMA kernels; with DROP, without RAGGED): keep bits from the precomputed words (common.hpp
+// attn_dropmask_words) instead of one hash per element.
+template <bool DROP, bool RAGGED, bool MW>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                   const bf16_t* __restrict__ dctx,
                                                                   const float* __restrict__ lse,
                                                                   const float* __restrict__ delta,
                                                                   bf16_t* __restrict__ dqkv, int B, int Np, int A,
-                                                                  DropArgs dr) {
+                                                                  DropArgs dr, const unsigned* __restrict__ maskw) {
+    static_assert(!MW || (DROP && !RAGGED), "mask words: dropout on, whole 128-token blocks");
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][TT * HD];  // [buffer][K|V]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -163,11 +166,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
         }
     };
     const int nkt = (Np + TT - 1) / TT;
+    const unsigned long* mrow = nullptr;  // this wave's lane masks: 16 per 32-key block, wave-uniform -> scalar loads
+    if (MW) {
+        const int nb = Np >> 5, qg = at.rt * 4 + __builtin_amdgcn_readfirstlane(wave);
+        mrow = (const unsigned long*)maskw + ((size_t)((b * A + head) * nb + qg) * nb) * 16;
+    }
+    TileMasks lm;
+    if (MW) lm.load(mrow);
     gload(0);
     swrite(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
+        if (MW) lm.wait();
         gload(min(kt + 1, nkt - 1));
         const bf16_t* Ks = lds[buf][0];
         const bf16_t* Vs = lds[buf][1];
@@ -199,8 +210,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
                 const float p0 = __builtin_amdgcn_exp2f(st[kb][r] * c), p1 = __builtin_amdgcn_exp2f(st[kb][r + 1] * c);
                 float d0, d1;
                 if (DROP) {
-                    const float m0 = drop_keep(dkey, (unsigned)k0, dr.thresh) ? dr.scale : 0.f;
-                    const float m1 = drop_keep(dkey, (unsigned)k1, dr.thresh) ? dr.scale : 0.f;
+                    float m0, m1;
+                    if (MW) {
+                        m0 = mask_select(lm.reg(kb, r), dr.scale);
+                        m1 = mask_select(lm.reg(kb, r + 1), dr.scale);
+                    } else {
+                        m0 = drop_keep(dkey, (unsigned)k0, dr.thresh) ? dr.scale : 0.f;
+                        m1 = drop_keep(dkey, (unsigned)k1, dr.thresh) ? dr.scale : 0.f;
+                    }
                     d0 = p0 * fmaf(dp[kb][r], m0, ndelta);
                     d1 = p1 * fmaf(dp[kb][r + 1], m1, ndelta);
                 } else {
@@ -222,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
                                                                      0, 0, 0);
             }
         }
+        if (MW) lm.load(mrow + (size_t)min(kt + 1, nkt - 1) * 32);   // next tile's lane masks (see TileMasks)
         swrite(buf ^ 1);
         __syncthreads();
     }
@@ -264,13 +282,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
 }
 
 // ---------------------------------------------------------------------------------- dK, dV (patch keys)
-template <bool DROP, bool RAGGED>
+template <bool DROP, bool RAGGED, bool MW>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                    const bf16_t* __restrict__ dctx,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ delta,
                                                                    bf16_t* __restrict__ dqkv, int B, int Np, int A,
-                                                                   DropArgs dr) {
+                                                                   DropArgs dr, const unsigned* __restrict__ maskw) {
+    static_assert(!MW || (DROP && !RAGGED), "mask words: dropout on, whole 128-token blocks");
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][TT * HD];  // [buffer][Q|dO]
     __shared__ __attribute__((aligned(16))) float stats[2][3][TT];      // -lse / c, -delta, dropout key of the tile's queries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -301,6 +320,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
     f32x4 rq[2], rd[2];
     float rs = 0.f, rdl = 0.f;
     unsigned rkey = 0;
+    // mask words of this lane's KEY (both lane halves the same key): one word per 32-query group, bit = query.
+    // Word position inside the key's 32-key block: 2 r + h with key = kappa(r, h).
+    unsigned nw[2] = {0u, 0u};
+    const unsigned* mcol = nullptr;
+    if (MW) {
+        const int nb = Np >> 5;
+        const int pos = 2 * ((li & 3) + 4 * (li >> 3)) + ((li >> 2) & 1);
+        mcol = maskw + ((size_t)((b * A + head) * nb) * nb + (nk >> 5)) * 32 + pos;   // + qg * nb * 32
+    }
     auto gload = [&](int qt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -309,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
             const size_t row = row0 + q;
             rq[i] = *(const f32x4*)(qkv + row * ld + head * HD + 8 * lc);
             rd[i] = *(const f32x4*)(dctx + row * (size_t)D + head * HD + 8 * lc);
+            if (MW) nw[i] = mcol[(size_t)(qt * 2 + i) * (Np >> 5) * 32];
         }
         if (tid < TT) {
             const int q = qt * TT + tid;
@@ -318,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
             rs = ok ? -lse[si] * inv_c : -INFINITY;
             rdl = ok ? -delta[si] : 0.f;
             // the query's dropout key, hashed ONCE per query here instead of once per (query, key) element below
-            if (DROP) rkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + q));
+            if (DROP && !MW) rkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + q));
         }
     };
     auto swrite = [&](int buf) {
@@ -340,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
     __syncthreads();
     for (int qt = 0; qt < nqt; ++qt) {
         const int buf = qt & 1;
+        const unsigned cw[2] = {nw[0] >> (4 * lh), nw[1] >> (4 * lh)};   // bit 8 g4 + e = register 4 g4 + e of this lane half
         gload(min(qt + 1, nqt - 1));
         const bf16_t* Qs = lds[buf][0];
         const bf16_t* Os = lds[buf][1];
@@ -354,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                 const f32x4 a = *(const f32x4*)&stats[buf][0][q0];
                 const f32x4 d4 = *(const f32x4*)&stats[buf][1][q0];
                 f32x4 k4 = {0.f, 0.f, 0.f, 0.f};
-                if (DROP) k4 = *(const f32x4*)&stats[buf][2][q0];
+                if (DROP && !MW) k4 = *(const f32x4*)&stats[buf][2][q0];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     st[4 * g4 + e] = a[e];
@@ -378,8 +408,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
             for (int r = 0; r < 16; r += 2) {
                 const float p0 = __builtin_amdgcn_exp2f(st[r] * c), p1 = __builtin_amdgcn_exp2f(st[r + 1] * c);
                 if (DROP) {
-                    const float m0 = drop_keep(rk16[r], (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
-                    const float m1 = drop_keep(rk16[r + 1], (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                    float m0, m1;
+                    if (MW) {   // 0 / -1 from the sign-extended bit, ANDed with the bits of 1 / (1 - p)
+                        const unsigned sb = __float_as_uint(dr.scale);
+                        m0 = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)cw[qb], 8 * (r >> 2) + (r & 3), 1) & sb);
+                        m1 = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)cw[qb], 8 * (r >> 2) + (r & 3) + 1, 1) & sb);
+                    } else {
+                        m0 = drop_keep(rk16[r], (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                        m1 = drop_keep(rk16[r + 1], (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                    }
                     pp[r >> 1] = pack2_bf16(p0 * m0, p1 * m1);  // dropped P (what multiplied V in the forward)
                     pd[r >> 1] = pack2_bf16(p0 * fmaf(dp[r], m0, dl[r]), p1 * fmaf(dp[r + 1], m1, dl[r + 1]));
                 } else {
@@ -539,19 +576,21 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_bf16_kernel(const bf16_t* __
 
 template <bool DROP>
 int launch_bwd(const bf16_t* qkv, const bf16_t* dctx, const float* lse, const float* dvec, bf16_t* dqkv, int B, int Np,
-               int A, DropArgs dr, hipStream_t s) {
+               int A, DropArgs dr, hipStream_t s, const unsigned* maskw) {
     const dim3 grid((unsigned)((Np + TB - 1) / TB) * A * B);  // 1-D: attn_tile() places the tiles
-    if (Np % TB == 0) {
-        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DROP, false>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
-        VITSEG_LAUNCH_CHECK("attn_bwd_dq_bf16");
-        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DROP, false>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
-        VITSEG_LAUNCH_CHECK("attn_bwd_dkv_bf16");
-    } else {
-        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DROP, true>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
-        VITSEG_LAUNCH_CHECK("attn_bwd_dq_bf16");
-        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DROP, true>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
-        VITSEG_LAUNCH_CHECK("attn_bwd_dkv_bf16");
-    }
+#define VITSEG_BWD(RG, MWORDS)                                                                                         \
+    do {                                                                                                               \
+        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DROP, RG, MWORDS>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec,   \
+                           dqkv, B, Np, A, dr, maskw);                                                                 \
+        VITSEG_LAUNCH_CHECK("attn_bwd_dq_bf16");                                                                       \
+        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DROP, RG, MWORDS>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec,  \
+                           dqkv, B, Np, A, dr, maskw);                                                                 \
+        VITSEG_LAUNCH_CHECK("attn_bwd_dkv_bf16");                                                                      \
+    } while (0)
+    if (Np % TB != 0) VITSEG_BWD(true, false);
+    else if (DROP && maskw) VITSEG_BWD(false, DROP);
+    else VITSEG_BWD(false, false);
+#undef VITSEG_BWD
     hipLaunchKernelGGL(attn_bwd_cls_bf16_kernel<DROP>, dim3(A, B), dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
     VITSEG_LAUNCH_CHECK("attn_bwd_cls_bf16");
     return VITSEG_OK;
@@ -560,13 +599,13 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* dctx, const float* lse, const fl
 }  // namespace
 
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dvec,
-                              void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s) {
+                              void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s, const unsigned* maskw) {
     VITSEG_CHECK_ARG(qkv && ctx && dctx && lse && dvec && dqkv, VITSEG_EINVAL, "attention_bwd_bf16: null pointer");
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3((unsigned)(((size_t)B * (Np + 1) * A * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ctx,
                        (const bf16_t*)dctx, dvec, B, Np, A);
     VITSEG_LAUNCH_CHECK("attn_delta_bf16");
-    return dr.thresh ? launch_bwd<true>((const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s)
-                     : launch_bwd<false>((const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s);
+    return dr.thresh ? launch_bwd<true>((const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s, maskw)
+                     : launch_bwd<false>((const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s, nullptr);
 }
 
 }  // namespace vitseg

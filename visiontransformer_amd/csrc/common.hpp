@@ -88,11 +88,15 @@ __host__ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned k, unsig
 // the attention kernels evaluate it for every element of the N x N probabilities in the forward and in both backward
 // kernels, where two 32-bit multiplies per hash (quarter rate) were ~ 5 ms of a training step.  Statistics (keep rate,
 // pair / neighbour / row / layer correlations, bit balance) are those of fmix32 (tests/test_host_cpu.py).
-__host__ __device__ __forceinline__ bool drop_keep(unsigned key, unsigned minor, unsigned thresh) {
-    unsigned h = mad24(minor >> 1, 0x9E3779u, key);
+__host__ __device__ __forceinline__ unsigned drop_pair_hash(unsigned key, unsigned pair) {
+    unsigned h = mad24(pair, 0x9E3779u, key);
     h ^= h >> 15;
     h = mad24(h, 0x85EBCBu, h >> 9);
     h ^= h >> 14;
+    return h;  // low half decides minor = 2 pair, high half minor = 2 pair + 1
+}
+__host__ __device__ __forceinline__ bool drop_keep(unsigned key, unsigned minor, unsigned thresh) {
+    const unsigned h = drop_pair_hash(key, minor >> 1);
     return ((minor & 1u) ? (h >> 16) : (h & 0xffffu)) >= thresh;
 }
 struct DropArgs {
@@ -101,6 +105,47 @@ struct DropArgs {
     unsigned stream;
     float scale;      // 1 / (1 - p)
 };
+
+// Attention-probability keep bits as precomputed words (attention_dropmask.hip), patch queries x patch keys of one
+// (image, head) pair bh, Np a multiple of 128, nb = Np / 32:
+//   W[((bh * nb + qg) * nb + kblk) * 32 + 2 r + h]   bit j = keep(query 32 qg + j, key 32 kblk + kappa(r, h)),
+//   kappa(r, h) = (r & 3) + 8 (r >> 2) + 4 h   (the key an MFMA 32x32 accumulator register r holds on lane half h).
+// The 64-bit pair (2 r, 2 r + 1) is therefore the lane mask of accumulator register r in the kernels that put a QUERY
+// on each lane (forward, dQ): a scalar load and one v_cndmask per element replace the hash.  The dK/dV kernel (a KEY on
+// each lane) reads its key's word per 32-query group and tests bit = query.
+inline size_t attn_dropmask_words(int B, int Np, int A) { return (size_t)B * A * (Np / 32) * Np; }
+// The four 512-bit scalar loads of one 64-key tile's lane masks (2 blocks of 32 keys x 16 accumulator registers), issued
+// by hand at the END of the previous loop iteration: SMEM shares lgkmcnt with the LDS and returns out of order, so a
+// scalar load in flight turns every LDS wait behind it into a full drain -- placed before the tile-end barrier it has
+// the whole staging wait to land.  mask_wait() (top of the iteration) is the only wait the consumer needs.
+typedef unsigned long u64x8 __attribute__((ext_vector_type(8)));
+struct TileMasks {
+    u64x8 v[4];  // v[2 kb + (r >> 3)][r & 7] = lane mask of register r of key block kb
+    __device__ __forceinline__ void load(const unsigned long* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile(
+            "s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\t"
+            "s_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0"
+            : "=&s"(v[0]), "=&s"(v[1]), "=&s"(v[2]), "=&s"(v[3])
+            : "s"(p));
+#endif
+    }
+    __device__ __forceinline__ void wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]));
+#endif
+    }
+    __device__ __forceinline__ unsigned long reg(int kb, int r) const { return v[2 * kb + (r >> 3)][r & 7]; }
+};
+__device__ __forceinline__ float mask_select(unsigned long lanes, float v) {  // lanes: wave-uniform 64-bit mask
+#if defined(__HIP_DEVICE_COMPILE__)
+    float o;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(lanes));
+    return o;
+#else
+    return v;
+#endif
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

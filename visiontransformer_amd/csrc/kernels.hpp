@@ -91,10 +91,14 @@ int launch_attention_x3_main(const float* qkv, float* ctx, int B, int Np, int A,
 // dqkv[Mt,3D] from dctx[Mt,D]; dvec: scratch fp32 [B, A, Np+1]
 int launch_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dvec,
                              float* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s);
+// maskw: optional precomputed keep-bit words of this layer's attention dropout (launch_attn_dropmask; common.hpp
+// attn_dropmask_words) -- used when dropout is on and Np % 128 == 0, otherwise the kernels hash per element
 int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s,
-                          bool f16 = false);
+                          bool f16 = false, const unsigned* maskw = nullptr);
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dvec,
-                              void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s);
+                              void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s,
+                              const unsigned* maskw = nullptr);
+int launch_attn_dropmask(unsigned* W, int B, int Np, int A, DropArgs dr, hipStream_t s);
 
 // seg_head.2 (1x1 conv) on the ReLU'd mid features -> NCHW low-res logits (a11)
 int launch_head1x1(const float* F, const float* W2, const float* b2, float* Z, int B, int Np, int C, hipStream_t s);

@@ -409,9 +409,14 @@ int vitseg_op_attention_bwd_f32(const float* qkv, const float* dctx, float* ctx_
 }
 
 // bf16 forward (saving the log-sum-exp, optional attention-probability dropout) + backward of the attention core
+size_t vitseg_attention_dropmask_bytes(int batch, int num_patches, int num_heads) {
+    return batch > 0 && num_heads > 0 && num_patches > 0 && num_patches % 128 == 0
+               ? attn_dropmask_words(batch, num_patches, num_heads) * sizeof(unsigned) : 0;
+}
+
 int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_out, float* lse_out, float* scratch,
                                  void* dqkv, int batch, int num_patches, int num_heads, float dropout_p,
-                                 uint32_t dropout_seed, uint32_t dropout_stream, void* stream) {
+                                 uint32_t dropout_seed, uint32_t dropout_stream, void* dropmask_words, void* stream) {
     VITSEG_CHECK_ARG(qkv && dctx && ctx_out && lse_out && scratch && dqkv, VITSEG_EINVAL, "attention_bwd: null pointer");
     VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "attention_bwd: dropout_p %f", dropout_p);
     DropArgs d{};
@@ -422,9 +427,18 @@ int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_ou
         d.stream = dropout_stream;
         d.scale = 1.0f / (1.0f - dropout_p);
     }
-    if (int rc = launch_attention_bf16(qkv, ctx_out, lse_out, batch, num_patches, num_heads, d, (hipStream_t)stream)) return rc;
+    const unsigned* mw = nullptr;
+    if (dropmask_words) {
+        VITSEG_CHECK_ARG(d.thresh && num_patches % 128 == 0, VITSEG_EINVAL,
+                         "attention_bwd: mask words need dropout_p > 0 and num_patches %% 128 == 0");
+        if (int rc = launch_attn_dropmask((unsigned*)dropmask_words, batch, num_patches, num_heads, d, (hipStream_t)stream))
+            return rc;
+        mw = (const unsigned*)dropmask_words;
+    }
+    if (int rc = launch_attention_bf16(qkv, ctx_out, lse_out, batch, num_patches, num_heads, d, (hipStream_t)stream, false, mw))
+        return rc;
     return launch_attention_bwd_bf16(qkv, ctx_out, dctx, lse_out, scratch, dqkv, batch, num_patches, num_heads, d,
-                                     (hipStream_t)stream);
+                                     (hipStream_t)stream, mw);
 }
 
 int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out,

@@ -15,6 +15,7 @@ namespace {
 // ---- training workspace: per-layer saved activations + backward temporaries (all fp32) ----
 struct LayerBufs {
     size_t xin, h1, qkv, ctx, lse, xmid, h2, upre, uact;
+    size_t dropw;  // bf16 path, Np % 128 == 0: keep-bit words of the attention dropout (written by the forward, read by the backward)
 };
 struct TrainPlan {
     size_t Mt, Mp;
@@ -52,6 +53,7 @@ TrainPlan make_train_plan(const Shape& s, int B, int precision) {
     p.lb.h2 = take(MtD / 4 * act);
     p.lb.upre = take(MtI / 4 * act);
     p.lb.uact = take(MtI / 4 * act);
+    p.lb.dropw = take(lp && s.Np % 128 == 0 ? attn_dropmask_words(B, s.Np, s.A) * 4 : 0);
     p.layer_stride = off;
     p.layer0 = 0;
     off = p.layer_stride * s.L;
@@ -148,6 +150,10 @@ struct Ctx {
         }
         return d;
     }
+    // keep-bit words of layer l's attention dropout, or null (dropout off / geometry without whole 128-token blocks)
+    const unsigned* dropw(int l) const {
+        return lp && drop_p > 0.f && s.Np % 128 == 0 && !getenv("VITSEG_NO_DROPMASK") ? (const unsigned*)LV(l, p.lb.dropw) : nullptr;
+    }
     const unsigned short* params_lp;
     const unsigned short* WL(int t, int l = 0) const { return params_lp + tensor_offset(lay, t, l); }
     void* LV(int l, size_t off) const { return (void*)(ws + p.layer0 + (size_t)l * p.layer_stride + off); }
@@ -235,7 +241,10 @@ int forward_train_bf16(Ctx& c, const float* x, float* logits) {
         }
         {
             ProfScope ps(VITSEG_K_TRAIN_ATTN_FWD, attn_flops(c, 4), st);
-            if ((rc = launch_attention_bf16(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, c.dr(l, 1), st))) return rc;
+            const unsigned* mw = c.dropw(l);
+            if (mw && (rc = launch_attn_dropmask((unsigned*)mw, batch, s.Np, s.A, c.dr(l, 1), st))) return rc;
+            if ((rc = launch_attention_bf16(QKV, CTX, c.L(l, c.p.lb.lse), batch, s.Np, s.A, c.dr(l, 1), st, false, mw)))
+                return rc;
         }
         g = lin(CTX, c.WL(VITSEG_T_WO, l), c.W(VITSEG_T_BO, l), Xin, Xmid, Mt, D, D, D, D);
         g.drop = c.dr(l, 2);
@@ -385,7 +394,7 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
         {
             ProfScope ps(VITSEG_K_TRAIN_ATTN_BWD, attn_flops(c, 10), st);
             if ((rc = launch_attention_bwd_bf16(c.LV(l, c.p.lb.qkv), c.LV(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
-                                                c.T(c.p.dvec), dQKV, B, s.Np, s.A, c.dr(l, 1), st)))
+                                                c.T(c.p.dvec), dQKV, B, s.Np, s.A, c.dr(l, 1), st, c.dropw(l))))
                 return rc;
         }
         if ((rc = launch_colsum(dQKV, 1, G(VITSEG_T_BQKV, l), scratch, Mt, 3 * D, 3 * D, st))) return rc;
