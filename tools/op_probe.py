@@ -26,6 +26,7 @@ ap.add_argument("--A", type=int, default=12)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--drop", type=float, default=0.0)
+ap.add_argument("--aux", action="store_true", help="linear_ex, epi 1: also write the saved GELU derivative")
 ap.add_argument("--words", action="store_true", help="attn_bwd: dropout keep bits as precomputed mask words")
 a = ap.parse_args()
 dev = "cuda:0"
@@ -60,8 +61,10 @@ elif a.op == "linear_ex":   # 16-bit linear with every epilogue (0 bias, 1 GELU,
     b = torch.randn(a.N, device=dev)
     R = torch.randn(a.M, a.N, device=dev).to(torch.float32 if a.epi == 2 else torch.bfloat16) if a.epi in (2, 5) else None
     C = R if a.epi == 2 else torch.zeros(a.M, a.N, device=dev, dtype=torch.bfloat16)
+    aux = torch.zeros(a.M, a.N, device=dev, dtype=torch.bfloat16) if a.aux else None
     run = lambda: _lib.check(L.vitseg_op_linear_h16_ex(A.data_ptr(), W.data_ptr(), b.data_ptr() if a.epi != 5 else None,
-                                                       R.data_ptr() if R is not None else None, C.data_ptr(), None, a.M, a.N,
+                                                       R.data_ptr() if R is not None else None, C.data_ptr(),
+                                                       aux.data_ptr() if a.aux else None, a.M, a.N,
                                                        a.K, a.epi, 0, 0, None, 0, 0.0, 0, 0, st))
     work = 2.0 * a.M * a.N * a.K
 elif a.op == "linear" and a.bf16:

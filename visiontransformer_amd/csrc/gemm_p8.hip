@@ -18,7 +18,9 @@
 //   * The accumulators hold C TRANSPOSED (MFMA A operand = W rows, B operand = activation rows): a lane then owns 4
 //     consecutive output columns of one row, which it parks as one 16-byte LDS write in a wave-private 4 KiB
 //     staging slab (outside the ring, so the operand stream keeps flowing); the slab is read back row-wise for
-//     the bias / GELU / residual / dropout arithmetic and whole-line global stores.
+//     the bias / GELU / residual / dropout arithmetic and whole-line global stores.  (Storing straight from the
+//     accumulator layout -- 8 / 16 bytes per lane, 32 / 64 contiguous bytes per row and instruction, no LDS round
+//     trip -- was measured 4-25 % slower on every training shape: partial-line writes.)
 // TT = 1 is the weight-gradient form  C[M,N] = sum_k A[k][m] W[k][n]  (dW = dY^T X: both operands lie [token][column],
 // the reduction runs over the token rows, split over `splitk` slices that write fp32 partial tiles): the same ring,
 // phases and stream, but a half-tile is [64 tokens][128 columns] (256-byte rows, 16-byte chunk c of row r stored at
