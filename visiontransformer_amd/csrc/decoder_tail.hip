@@ -1,4 +1,6 @@
 // Decoder tail: seg_head.2 (1x1 conv), bilinear upsample, sigmoid -> argmax mask.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace vitseg {
@@ -70,16 +72,49 @@ __device__ __forceinline__ float sigmoid_aten(float x) {
 // Thread = a 4 (x) by UPR (y) block of output pixels: the x taps are computed once, and the two horizontally
 // interpolated source rows (`top`, `bot`) are reused while consecutive output rows keep the same source rows (at
 // 16x up-scaling 15 of 16 do; the test is wave-uniform because a wave covers one output row band).
+// STAGED (a block = whole row bands of one image, launch_upsample decides): the few low-res rows the block's output rows
+// interpolate between are copied to LDS for all classes FIRST, so the class loop issues no global reads.  With C = 17
+// the kernel writes 581 MB per launch; a dependent global gather per class then waits behind the saturated write
+// queues (17 serialized round trips of several us each: 3.3 TB/s) -- from LDS the loop is a pure store stream.
 constexpr int UPR = 4;
+template <bool STAGED>
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ Z, float* __restrict__ logits,
                                                        uint8_t* __restrict__ mask, int B, int C, int g, int S) {
+    extern __shared__ __attribute__((aligned(16))) float zs[];   // STAGED: [class][source row - ymin][g]
+    // STAGED: pixels whose raw top-2 margin does not settle the sigmoid argmax are queued here and resolved densely after
+    // the main pass (one lane per queued pixel) -- inside the main pass a single such pixel would send its whole wave
+    // (256 pixels) through the exact-sigmoid loop over all classes, which made the mask cost 2x the logits stream
+    __shared__ unsigned amb_n;
+    __shared__ unsigned amb_px[STAGED ? 256 * UPR * 4 : 1];
     const int quads = S >> 2, bands = S / UPR;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)B * bands * quads) return;
+    const float scale = (float)g / (float)S;
+    int ymin = 0, nr = 0, Yf = 0, bimg = 0;
+    if (STAGED) {
+        const int bpb = 256 / quads;                                   // bands per block (whole number, same image)
+        const size_t band0 = (size_t)blockIdx.x * bpb;
+        Yf = (int)(band0 % bands) * UPR;
+        bimg = (int)(band0 / bands);
+        if (threadIdx.x == 0) amb_n = 0;
+        int ya, yb, yc, yd;
+        float w0, w1;
+        taps(Yf, scale, g, ya, yb, w0, w1);
+        taps(Yf + bpb * UPR - 1, scale, g, yc, yd, w0, w1);
+        ymin = ya;
+        nr = yd - ya + 1;
+        if (bimg < B) {
+            const int per = nr * g;
+            for (int i = threadIdx.x; i < C * per; i += 256) {
+                const int c = i / per, rem = i - c * per;
+                zs[i] = Z[((size_t)bimg * C + c) * g * g + (size_t)ymin * g + rem];
+            }
+        }
+        __syncthreads();
+    }
+    if (!STAGED && idx >= (size_t)B * bands * quads) return;   // STAGED grids are whole blocks (launch_upsample)
     const int xq = (int)(idx % quads);
     const int Y0 = (int)((idx / quads) % bands) * UPR;
     const int b = (int)(idx / ((size_t)quads * bands));
-    const float scale = (float)g / (float)S;
     int x0[4], x1[4];
     float wx0[4], wx1[4];
 #pragma unroll
@@ -106,7 +141,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
             arg[r][e] = 0;
         }
     auto hrow = [&](int c, int y) {  // source row y of class c interpolated along x at this thread's 4 columns
-        const float* z = Z + (((size_t)b * C + c) * g + y) * g;
+        const float* z = STAGED ? zs + (c * nr + (y - ymin)) * g : Z + (((size_t)b * C + c) * g + y) * g;
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = __fmaf_rn(z[x0[e]], wx0[e], __fmul_rn(z[x1[e]], wx1[e]));
@@ -146,9 +181,12 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float at = fabsf(t1[r][e]), margin = t1[r][e] - t2[r][e];
-                amb = amb || !((at <= 2.0f && margin >= 1e-4f) || (at <= 8.0f && margin >= 4e-3f));
+                const bool a1 = !((at <= 2.0f && margin >= 1e-4f) || (at <= 8.0f && margin >= 4e-3f));
+                if (STAGED && a1)   // resolved after the main pass (the raw argmax written below is overwritten)
+                    amb_px[atomicAdd(&amb_n, 1u)] = (unsigned)(((Y0 + r - Yf) << 12) | (4 * xq + e));
+                amb = amb || a1;
             }
-            if (amb) {  // exact path: ATen's fp32 sigmoid restated (sigmoid_aten), first maximal class wins
+            if (!STAGED && amb) {  // exact path: ATen's fp32 sigmoid restated (sigmoid_aten), first maximal class wins
                 float best[4];
                 for (int c = 0; c < C; ++c) {
                     const f32x4 top = hrow(c, y0[r]), bot = hrow(c, y1[r]);
@@ -169,6 +207,31 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
             m4.z = (unsigned char)arg[r][2];
             m4.w = (unsigned char)arg[r][3];
             *(uchar4*)(mask + ((size_t)b * S + Y0 + r) * S + 4 * xq) = m4;
+        }
+    }
+    if (STAGED && mask) {
+        __syncthreads();   // the queue is complete and this block's raw-argmax bytes are written
+        const unsigned n_amb = amb_n;
+        for (unsigned i = threadIdx.x; i < n_amb; i += 256) {
+            const int Y = Yf + (int)(amb_px[i] >> 12), X = (int)(amb_px[i] & 0xfffu);
+            int ya, yb, xa, xb;
+            float wya, wyb, wxa, wxb;
+            taps(Y, scale, g, ya, yb, wya, wyb);
+            taps(X, scale, g, xa, xb, wxa, wxb);
+            float best = 0.f;
+            int barg = 0;
+            for (int c = 0; c < C; ++c) {   // the same fma placement as the main pass, then ATen's fp32 sigmoid
+                const float* zt = zs + (c * nr + (ya - ymin)) * g;
+                const float* zb = zs + (c * nr + (yb - ymin)) * g;
+                const float top = __fmaf_rn(zt[xa], wxa, __fmul_rn(zt[xb], wxb));
+                const float bot = __fmaf_rn(zb[xa], wxa, __fmul_rn(zb[xb], wxb));
+                const float sg = sigmoid_aten(__fmaf_rn(top, wya, __fmul_rn(bot, wyb)));
+                if (c == 0 || sg > best) {
+                    best = sg;
+                    barg = c;
+                }
+            }
+            mask[((size_t)bimg * S + Y) * S + X] = (unsigned char)barg;
         }
     }
 }
@@ -272,8 +335,18 @@ int launch_upsample(const float* Z, float* logits, uint8_t* mask, int B, int C, 
     VITSEG_CHECK_ARG(Z && (logits || mask), VITSEG_EINVAL, "upsample: null pointer");
     VITSEG_CHECK_ARG(S % 4 == 0 && C >= 1 && C <= 255, VITSEG_ESHAPE, "upsample: S %% 4 != 0 or C out of range");
     const size_t n = (size_t)B * (S / UPR) * (S / 4);
-    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Z, logits, mask, B, C, g,
-                       S);
+    const int quads = S / 4, bands = S / UPR;
+    // staged variant: a block must be whole bands of one image, and the source rows of its output rows must fit the LDS
+    const bool whole = quads <= 256 && 256 % quads == 0 && bands % (256 / quads) == 0;
+    const int rows_out = whole ? (256 / quads) * UPR : 0;
+    const size_t nr_max = (size_t)((double)rows_out * g / S) + 3;
+    const size_t smem = (size_t)C * nr_max * g * sizeof(float);
+    if (whole && smem <= 48 * 1024 && !getenv("VITSEG_UPSAMPLE_GLOBAL"))
+        hipLaunchKernelGGL(upsample_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), smem, s, Z, logits, mask, B,
+                           C, g, S);
+    else
+        hipLaunchKernelGGL(upsample_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Z, logits, mask, B, C,
+                           g, S);
     VITSEG_LAUNCH_CHECK("upsample");
     return VITSEG_OK;
 }
