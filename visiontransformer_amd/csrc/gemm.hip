@@ -1197,6 +1197,13 @@ int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
             return launch_thin_rows_h16<T>(w, epi, s, sp);
         }
     }
+    // A ragged last row tile (the CLS rows) is free when it fits into the persistent kernel's last, partly empty round
+    // (batch 32: 384 + 3 tiles of the N = 768 linears over 256 CUs): no side launch, no reducing kernel.
+    if (amode == A_PLAIN && a_in.M % 256 != 0 && a_in.M % 256 <= 128 && gemm_p8_applies(a_in, epi) &&
+        gemm_p8_rounds(a_in.M, a_in.N) == gemm_p8_rounds(a_in.M - a_in.M % 256, a_in.N) && !getenv("VITSEG_NO_RAGGED_P8")) {
+        a.thin_scratch = nullptr;
+        return launch_gemm_p8(a, epi, s, std::is_same<T, f16_t>::value);
+    }
     if (amode == A_PLAIN && thin_split_applies(a_in, epi, true) && (a_in.M - a_in.thin_rows) % LBM == 0 && a_in.K % 64 == 0) {
         if (int rc = launch_thin_rows_h16<T>(a_in, epi, s)) return rc;  // CLS rows: split-K side launch (GemmArgs)
         a.M = a_in.M - a_in.thin_rows;

@@ -508,6 +508,12 @@ static int p8_num_cus() {
     return ncu;
 }
 
+// rounds of the persistent grid an NT launch with M rows takes (one 256 x 256 tile per CU and round)
+int gemm_p8_rounds(int M, int N) {
+    const int ncu = p8_num_cus();
+    return (((M + PT - 1) / PT) * (N / PT) + ncu - 1) / ncu;
+}
+
 template <typename T, typename OutT, int EPI, int TT>
 static int launch_p8_one(GemmArgs a, int items, hipStream_t s) {
     static bool attr_set = false;

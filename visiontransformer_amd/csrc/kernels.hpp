@@ -71,6 +71,7 @@ size_t wgrad_bf16_scratch_floats(int M, int N, int K);
 // 16-bit operands, fp32 accumulate; f16 selects IEEE half instead of bf16 (inference formats, common.hpp H16<>)
 int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s, bool f16 = false);
 // persistent 8-phase 256x256 kernel for the large plain linear layers (gemm_p8.hip); `applies` = shape / alignment test
+int gemm_p8_rounds(int M, int N);
 bool gemm_p8_applies(const GemmArgs& a, int epi);
 int launch_gemm_p8(const GemmArgs& a, int epi, hipStream_t s, bool f16);
 // the same kernel in its T-form x T-form guise (weight gradients, split over the token rows)
