@@ -409,10 +409,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                 const float p0 = __builtin_amdgcn_exp2f(st[r] * c), p1 = __builtin_amdgcn_exp2f(st[r + 1] * c);
                 if (DROP) {
                     float m0, m1;
-                    if (MW) {   // 0 / -1 from the sign-extended bit, ANDed with the bits of 1 / (1 - p)
+                    if (MW) {   // 0 / -1 from the sign-extended bit, ANDed with the bits of 1 / (1 - p): two VALU ops
+                        // (asm: hipcc rewrites the intrinsic form into and + compare + select)
                         const unsigned sb = __float_as_uint(dr.scale);
-                        m0 = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)cw[qb], 8 * (r >> 2) + (r & 3), 1) & sb);
-                        m1 = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)cw[qb], 8 * (r >> 2) + (r & 3) + 1, 1) & sb);
+                        int b0, b1;
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(b0) : "v"(cw[qb]), "n"(8 * (r >> 2) + (r & 3)));
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(b1) : "v"(cw[qb]), "n"(8 * (r >> 2) + (r & 3) + 1));
+                        m0 = __uint_as_float((unsigned)b0 & sb);
+                        m1 = __uint_as_float((unsigned)b1 & sb);
                     } else {
                         m0 = drop_keep(rk16[r], (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
                         m1 = drop_keep(rk16[r + 1], (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
