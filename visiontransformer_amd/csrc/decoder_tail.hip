@@ -290,14 +290,22 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void ce_finish_kernel(const double* __restrict__ partial, int n, double inv_count,
-                                                        float* __restrict__ loss) {
-    __shared__ double red[256];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];  // fixed order per thread
-    red[threadIdx.x] = s;
+__global__ __launch_bounds__(1024) void ce_finish_kernel(const double* __restrict__ partial, int n, double inv_count,
+                                                         float* __restrict__ loss) {
+    __shared__ double red[1024];
+    // fixed assignment and order: 4 independent strided chains per thread (loads in flight), then a tree
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        s0 += partial[i];
+        s1 += partial[i + 1024];
+        s2 += partial[i + 2 * 1024];
+        s3 += partial[i + 3 * 1024];
+    }
+    for (; i < n; i += 1024) s0 += partial[i];
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
@@ -319,7 +327,7 @@ int launch_ce_loss(const float* Z, const void* target, int target_is_u8, float* 
         hipLaunchKernelGGL(ce_loss_kernel<long long>, dim3(nb), dim3(256), 0, s, Z, (const long long*)target, G,
                            partial, B, C, g, S, gscale);
     VITSEG_LAUNCH_CHECK("ce_loss");
-    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, partial, (int)nb, 1.0 / ((double)B * S * S), loss);
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(1024), 0, s, partial, (int)nb, 1.0 / ((double)B * S * S), loss);
     VITSEG_LAUNCH_CHECK("ce_finish");
     return VITSEG_OK;
 }

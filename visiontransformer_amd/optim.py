@@ -35,6 +35,7 @@ class FusedAdam(torch.optim.Optimizer):
                         p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
                         group["lr"], group["betas"][0], group["betas"][1], group["eps"], st["step"], grad_scale,
                         torch.cuda.current_stream().cuda_stream))
-                p._version  # noqa: B018  (in-place update through the raw pointer; bump the version below)
-                p.add_(0)   # marks the arena as modified so the bf16 shadow / cached views refresh
+                # the update went through the raw pointer: bump the version counter (no kernel) so the bf16 shadow of
+                # the arena and autograd's saved-tensor checks see the modification
+                torch.autograd.graph.increment_version(p)
         return loss
