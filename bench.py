@@ -453,6 +453,8 @@ def main():
         backend = os.environ.get("VITSEG_DIST_BACKEND", "nccl")
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
+        world = dist.get_world_size()   # what the process group (RCCL) reports, not what the environment asked for
+
     def barrier():
         if world > 1:
             dist.barrier()

@@ -39,6 +39,7 @@ class _LogitsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         grads, _ = ctx.model._backward(ctx.x, grad_logits=dlogits.to(torch.float32).contiguous(), drop=ctx.drop)
+        ctx.model._release_grad_buffer(grads)   # autograd owns it from here (as arena.grad, or summed into it)
         return grads, None, None
 
 
@@ -52,12 +53,13 @@ class _CELossFn(torch.autograd.Function):
         drop = model._next_dropout()
         model._forward_train(x, want_logits=False, drop=drop)
         grads, loss = model._backward(x, target=target, drop=drop, loss_scale=1.0 if grad_scale is None else grad_scale)
-        ctx.grads = grads
+        ctx.grads, ctx.model = grads, model
         ctx.prescaled = grad_scale is not None
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
+        ctx.model._release_grad_buffer(ctx.grads)   # autograd owns it from here (as arena.grad, or summed into it)
         return (ctx.grads if ctx.prescaled else ctx.grads * dloss), None, None, None, None
 
 
@@ -287,12 +289,34 @@ class ViTSegmentationModel(nn.Module):
             self._buckets = (BucketReducer(ranges, self.grad_bucket_mb), events, handles, torch.cuda.Stream())
         return self._buckets
 
+    def _take_grad_buffer(self) -> torch.Tensor:
+        """The arena-sized buffer vitseg_backward writes: ONE persistent tensor, reused step after step.  It cannot be
+        reused while it is still somebody's gradient: handed to an autograd node whose backward has not run yet
+        (`_grad_busy`, cleared by `_release_grad_buffer`), or installed as `arena.grad` (accumulation pending, or
+        `zero_grad(set_to_none=False)`); then this call gets a temporary of its own."""
+        buf = getattr(self, "_grad_buf", None)
+        pending = self.arena.grad
+        usable = (buf is not None and buf.shape == self.arena.shape and buf.device == self.arena.device
+                  and not getattr(self, "_grad_busy", False)
+                  and (pending is None or pending.data_ptr() != buf.data_ptr()))
+        if usable:
+            self._grad_busy = True
+            return buf
+        fresh = torch.empty_like(self.arena.data)
+        if buf is None or buf.shape != self.arena.shape or buf.device != self.arena.device:
+            self._grad_buf, self._grad_busy = fresh, True
+        return fresh
+
+    def _release_grad_buffer(self, grads: torch.Tensor) -> None:
+        if getattr(self, "_grad_buf", None) is not None and grads.data_ptr() == self._grad_buf.data_ptr():
+            self._grad_busy = False
+
     def _backward(self, x: torch.Tensor, target: Optional[torch.Tensor] = None,
                   grad_logits: Optional[torch.Tensor] = None, drop=(0.0, 0), loss_scale: float = 1.0):
         x = x.to(torch.float32).contiguous()
         B = x.shape[0]
         ws = self._train_workspace(B)
-        grads = torch.empty_like(self.arena.data)
+        grads = self._take_grad_buffer()
         loss = torch.zeros((), dtype=torch.float32, device=x.device) if target is not None else None
         overlap = self._overlap_active()
         with torch.cuda.device(x.device):
