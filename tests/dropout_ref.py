@@ -34,8 +34,7 @@ class Masks:
             m = minor.astype(np.uint32)
             h = mad24(m >> np.uint32(1), 0x9E3779, key)
             h ^= h >> np.uint32(15)
-            h = mad24(h, 0x85EBCB, h >> np.uint32(9))
-            h ^= h >> np.uint32(14)
+            h = (h * np.uint32(0x85EBCA6B)).astype(np.uint32)
             return np.where(m & np.uint32(1), h >> np.uint32(16), h & np.uint32(0xFFFF)) >= self.thresh
 
     def _gen(self, n_ref):  # reference token index (CLS first) -> generic index (CLS last)

@@ -121,6 +121,10 @@ def test_dropout_generator_statistics():
     assert abs(corr(a[..., :-1], a[..., 1:])) < 0.01        # neighbouring keys (the two halves of one hash)
     assert abs(corr(a[..., :-2], a[..., 2:])) < 0.01        # next pair
     assert abs(corr(a[:, :, :-1], a[:, :, 1:])) < 0.01      # neighbouring queries
+    for lag in (3, 4, 8, 32, 33):                           # further keys / queries, the two diagonals
+        assert abs(corr(a[..., :-lag], a[..., lag:])) < 0.01 and abs(corr(a[:, :, :-lag], a[:, :, lag:])) < 0.01
+    assert abs(corr(a[:, :, :-1, :-1], a[:, :, 1:, 1:])) < 0.01 and abs(corr(a[:, :, :-1, 1:], a[:, :, 1:, :-1])) < 0.01
+    assert abs(a.mean(axis=(0, 1, 2)).std() - np.sqrt(0.09 / (2 * 3 * 256))) < 3e-3   # per-key keep rates scatter like iid bits
     b = (m.attn(1, (2, 3, 256, 256)).numpy() > 0).astype(np.float64)
     assert abs(corr(a, b)) < 0.01                           # next layer
     r = (m.rows(0, 3, (2, 256, 192)).numpy() > 0).astype(np.float64)

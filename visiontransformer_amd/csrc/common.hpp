@@ -84,15 +84,15 @@ __host__ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned k, unsig
 #endif
 }
 // One hash decides TWO neighbouring elements (minor = 2j, 2j + 1): 16 bits each against thresh = round(p * 2^16).
-// The per-row key is a full fmix32 (once per row); the per-pair mixer is two 24-bit multiply-adds and two xor-shifts --
-// the attention kernels evaluate it for every element of the N x N probabilities in the forward and in both backward
-// kernels, where two 32-bit multiplies per hash (quarter rate) were ~ 5 ms of a training step.  Statistics (keep rate,
-// pair / neighbour / row / layer correlations, bit balance) are those of fmix32 (tests/test_host_cpu.py).
+// The per-row key is a full fmix32 (once per row); the per-pair mixer is one 24-bit multiply-add, one xor-shift and one
+// 32-bit multiply (4 VALU ops; v_mul_lo_u32 issues at full rate on gfx950, tools/probes/imul_rate.hip) -- it is
+// evaluated for every element of the N x N attention probabilities.  Statistics (keep rate, pair / neighbour / row /
+// diagonal / layer correlations at the 1e-3 level over 12 M samples, column and row means) are those of independent
+// bits (tests/test_host_cpu.py).
 __host__ __device__ __forceinline__ unsigned drop_pair_hash(unsigned key, unsigned pair) {
     unsigned h = mad24(pair, 0x9E3779u, key);
     h ^= h >> 15;
-    h = mad24(h, 0x85EBCBu, h >> 9);
-    h ^= h >> 14;
+    h *= 0x85EBCA6Bu;
     return h;  // low half decides minor = 2 pair, high half minor = 2 pair + 1
 }
 __host__ __device__ __forceinline__ bool drop_keep(unsigned key, unsigned minor, unsigned thresh) {
