@@ -161,7 +161,11 @@ int vitseg_op_attention_f16(const void* qkv, void* ctx, int batch, int num_patch
  * keep(seed, stream, row, col) of csrc/common.hpp, i.e. hidden dropout of modeling_vit.py:276,283. */
 int vitseg_op_linear_h16_ex(const void* A, const void* W, const float* bias, const void* R, void* C, void* aux, int M,
                             int N, int K, int epilogue, int f16, int thin_rows, float* scratch, size_t scratch_floats,
-                            float dropout_p, uint32_t dropout_seed, uint32_t dropout_stream, void* stream);
+                            float dropout_p, uint32_t dropout_seed, uint32_t dropout_stream, float* colsum_out,
+                            float* colsum_scratch, void* stream);
+/* colsum_out (epilogue 5, bf16; optional): the column sums of C [N] -- the bias gradient the backward needs next -- produced
+ * from the GEMM epilogue's per-tile partial sums; colsum_scratch: vitseg_op_colsum_scratch_floats(M, N) floats. */
+size_t vitseg_op_colsum_scratch_floats(int M, int N);
 /* bf16 weight gradient dW[M,N] (fp32) = dY^T X with dY = [K tokens][M], X = [K tokens][N] bf16 row-major (the form
  * autograd's linear backward meets: both operands lie token-major, the reduction runs over the token rows); split over
  * the token rows, fp32 partials in `scratch` (>= vitseg_op_wgrad_bf16_scratch_floats floats), fixed-order reduce.

@@ -287,6 +287,10 @@ def test_linear_h16_tile_variants(M, N, K, epi, extra, fmt, monkeypatch):
     scratch = torch.empty(16 * 64 * max(N, 3072), device=DEV) if thin else None
     p, seed, stream_id = (0.1, 0x1234ABCD, 13) if "drop" in extra else (0.0, 0, 0)
     aux = torch.zeros(M, N, device=DEV, dtype=dt) if "aux" in extra else None
+    cs_out = cs_scr = None
+    if epi == 5 and fmt == "bf16":   # every dGELU case also asks for the fused column sums (all dispatch paths)
+        cs_out = torch.full((N,), float("nan"), device=DEV)
+        cs_scr = torch.empty(_lib.lib().vitseg_op_colsum_scratch_floats(M, N), device=DEV)
     if epi == 2:
         R = _rand(M, N, seed=11)
         C = R.to(DEV)
@@ -309,8 +313,14 @@ def test_linear_h16_tile_variants(M, N, K, epi, extra, fmt, monkeypatch):
     _lib.check(_lib.lib().vitseg_op_linear_h16_ex(
         Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr() if bd is not None else None, Rp, C.data_ptr(),
         aux.data_ptr() if aux is not None else None, M, N, K, epi, int(fmt == "fp16"), thin,
-        scratch.data_ptr() if thin else None, scratch.numel() if thin else 0, p, seed, stream_id, _stream()))
+        scratch.data_ptr() if thin else None, scratch.numel() if thin else 0, p, seed, stream_id,
+        cs_out.data_ptr() if cs_out is not None else None, cs_scr.data_ptr() if cs_out is not None else None, _stream()))
     got = C.float().cpu().double()
+    if cs_out is not None:   # the bias gradient from the epilogue's per-tile partial sums (unrounded fp32 values), fixed order
+        # (the paths without the 8-phase kernel sum the bf16-rounded C instead: independent roundings of 2^-9 relative)
+        cref = ref.sum(dim=0)
+        tol = 4 * 2.0 ** -9 * (ref ** 2).sum(dim=0).sqrt() + 4e-7 * scale * M ** 0.5
+        assert ((cs_out.cpu().double() - cref).abs() <= tol).all()
     if epi == 2:      # fp32 output: fp32 accumulation error only
         assert (got - ref).abs().max().item() < 4e-7 * scale * (1.2 if p else 1.0) + 1e-5
     else:             # one rounding to the 16-bit format

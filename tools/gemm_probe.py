@@ -32,7 +32,7 @@ SHAPES = [("qkv", 2304, 768, 0), ("fc1+gelu", 3072, 768, 1), ("fc2+res", 768, 30
 def call(A, W, b, R, C, N, K, epi):
     _lib.check(L.vitseg_op_linear_h16_ex(A.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None,
                                          R.data_ptr() if R is not None else None, C.data_ptr(), None, M, N, K, epi,
-                                         int(a.fmt != "bf16"), 0, None, 0, 0.0, 0, 0, st))
+                                         int(a.fmt != "bf16"), 0, None, 0, 0.0, 0, 0, None, None, st))
 
 
 def timed(fn):

@@ -65,7 +65,7 @@ elif a.op == "linear_ex":   # 16-bit linear with every epilogue (0 bias, 1 GELU,
     run = lambda: _lib.check(L.vitseg_op_linear_h16_ex(A.data_ptr(), W.data_ptr(), b.data_ptr() if a.epi != 5 else None,
                                                        R.data_ptr() if R is not None else None, C.data_ptr(),
                                                        aux.data_ptr() if a.aux else None, a.M, a.N,
-                                                       a.K, a.epi, 0, 0, None, 0, 0.0, 0, 0, st))
+                                                       a.K, a.epi, 0, 0, None, 0, 0.0, 0, 0, None, None, st))
     work = 2.0 * a.M * a.N * a.K
 elif a.op == "linear" and a.bf16:
     A = torch.randn(a.M, a.K, device=dev).to(torch.bfloat16)

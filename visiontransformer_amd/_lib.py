@@ -33,7 +33,7 @@ EXPORTS = [
     "vitseg_resize_taps", "vitseg_resize_coeffs", "vitseg_nearest_index", "vitseg_preprocess_u8",
     "vitseg_resize_nearest_u8", "vitseg_eval_counts", "vitseg_paed_scratch_bytes", "vitseg_paed_multiclass_loss",
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32", "vitseg_op_linear_h16_ex",
-    "vitseg_op_wgrad_bf16", "vitseg_op_wgrad_bf16_scratch_floats", "vitseg_op_attention_bwd_bf16", "vitseg_attention_dropmask_bytes",
+    "vitseg_op_wgrad_bf16", "vitseg_op_wgrad_bf16_scratch_floats", "vitseg_op_attention_bwd_bf16", "vitseg_attention_dropmask_bytes", "vitseg_op_colsum_scratch_floats",
     "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
@@ -86,7 +86,9 @@ def lib() -> C.CDLL:
         l.vitseg_op_wgrad_bf16_scratch_floats.restype = sz
         l.vitseg_op_wgrad_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
         l.vitseg_op_linear_h16_ex.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, C.c_float,
-                                              C.c_uint32, C.c_uint32, vp]
+                                              C.c_uint32, C.c_uint32, vp, vp, vp]
+        l.vitseg_op_colsum_scratch_floats.argtypes = [i32, i32]
+        l.vitseg_op_colsum_scratch_floats.restype = sz
         l.vitseg_op_attention_f16.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_attention_f32x3.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_upsample_argmax.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]

@@ -441,7 +441,24 @@ inline int grid_for(size_t n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) 
 
 }  // namespace
 
-size_t colsum_scratch_floats(int M, int N) { return (size_t)((M + 255) / 256) * N; }
+// also holds the fused form's partial rows: two per 256-row tile of the 8-phase GEMM + the rows it did not cover (kernels.hpp)
+size_t colsum_scratch_floats(int M, int N) { return (size_t)(2 * ((M + 255) / 256) + 2) * N; }
+// column sums of the trailing rows of a 16-bit matrix into partial row `chunk0` (+ following), then the fixed-order reduce
+// over all `chunk0 + chunks` partial rows (the first chunk0 were written by the GEMM epilogue)
+int launch_colsum_finish_fused(const void* tail_rows, int tail, int chunk0, float* out, float* scratch, int N, int ld,
+                               hipStream_t s) {
+    int chunks = chunk0;
+    if (tail > 0) {
+        const int tc = (tail + 255) / 256;
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3((N + 255) / 256, tc), dim3(256), 0, s, (const bf16_t*)tail_rows,
+                           scratch + (size_t)chunk0 * N, tail, N, ld);
+        VITSEG_LAUNCH_CHECK("colsum_partial(tail)");
+        chunks += tc;
+    }
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, scratch, out, chunks, N);
+    VITSEG_LAUNCH_CHECK("colsum_finish");
+    return VITSEG_OK;
+}
 int launch_colsum(const void* X, int x_is_bf16, float* out, float* scratch, int M, int N, int ld, hipStream_t s) {
     const int chunks = (M + 255) / 256;
     if (x_is_bf16)

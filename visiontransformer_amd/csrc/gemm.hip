@@ -1188,8 +1188,11 @@ int launch_gemm_f32_bwd(const GemmArgs& a, int amode, int ta, int tb, int epi, h
 // bf16 operands (A and W), fp32 accumulate.  Output type follows the consumer: bf16 for tensors
 // that feed the next MFMA (q|k|v, MLP hidden), fp32 for the residual stream and the head features.
 template <typename T>
-int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
+// p8_rows: set to the number of leading rows whose column-sum partials the 8-phase kernel wrote (GemmArgs::colsum_*)
+int launch_gemm_h16_impl(const GemmArgs& a_in, int amode, int epi, hipStream_t s, int* p8_rows) {
     GemmArgs a = a_in;
+    const bool want_cs = a_in.colsum_out && a_in.colsum_scratch && epi == EPI_DGELU;
+    if (!want_cs) a.colsum_scratch = nullptr;
     if (amode == A_PLAIN) {
         if (const int sp = whole_split_applies(a_in, epi, 64)) {  // small batch: every row through K slices
             GemmArgs w = a_in;
@@ -1202,6 +1205,7 @@ int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
     if (amode == A_PLAIN && a_in.M % 256 != 0 && a_in.M % 256 <= 128 && gemm_p8_applies(a_in, epi) &&
         gemm_p8_rounds(a_in.M, a_in.N) == gemm_p8_rounds(a_in.M - a_in.M % 256, a_in.N) && !getenv("VITSEG_NO_RAGGED_P8")) {
         a.thin_scratch = nullptr;
+        if (want_cs) *p8_rows = a.M;
         return launch_gemm_p8(a, epi, s, std::is_same<T, f16_t>::value);
     }
     if (amode == A_PLAIN && thin_split_applies(a_in, epi, true) && (a_in.M - a_in.thin_rows) % LBM == 0 && a_in.K % 64 == 0) {
@@ -1220,9 +1224,13 @@ int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
         // (M = 65 600: 257 x 12 tiles over 256 CUs = 13 rounds for 12.05 rounds of work), so up to 128 trailing rows
         // (the CLS rows) go through the 128x128 kernel as a second, tiny launch with the same epilogue.
         const int tail = a.M % 256;
-        if (tail == 0 || tail > 128) return launch_gemm_p8(a, epi, s, std::is_same<T, f16_t>::value);
+        if (tail == 0 || tail > 128) {
+            if (want_cs) *p8_rows = a.M;
+            return launch_gemm_p8(a, epi, s, std::is_same<T, f16_t>::value);
+        }
         GemmArgs body = a, t = a;
         body.M = a.M - tail;
+        if (want_cs) *p8_rows = body.M;
         if (int rc = launch_gemm_p8(body, epi, s, std::is_same<T, f16_t>::value)) return rc;
         const size_t ro = (size_t)body.M;
         t.M = tail;
@@ -1271,6 +1279,18 @@ int launch_gemm_h16(const GemmArgs& a_in, int amode, int epi, hipStream_t s) {
     }
     set_error("gemm_bf16: unsupported amode/epilogue %d/%d", amode, epi);
     return VITSEG_EINVAL;
+}
+
+template <typename T>
+int launch_gemm_h16(const GemmArgs& a, int amode, int epi, hipStream_t s) {
+    int covered = 0;
+    if (int rc = launch_gemm_h16_impl<T>(a, amode, epi, s, &covered)) return rc;
+    if (!a.colsum_out) return VITSEG_OK;
+    VITSEG_CHECK_ARG(a.colsum_scratch && (std::is_same<T, bf16_t>::value), VITSEG_EINVAL, "gemm: column sums need bf16 + scratch");
+    if (covered > 0)   // per-tile partials are in the scratch; add the rows the persistent kernel did not cover and reduce
+        return launch_colsum_finish_fused((const T*)a.C + (size_t)covered * a.ldc, a.M - covered, 2 * ((covered + 255) / 256),
+                                          a.colsum_out, a.colsum_scratch, a.N, a.ldc, s);
+    return launch_colsum(a.C, 1, a.colsum_out, a.colsum_scratch, a.M, a.N, a.ldc, s);
 }
 
 int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s, bool f16) {

@@ -360,6 +360,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
                 }
             }
         };
+        constexpr bool COLSUM = EPI == EPI_DGELU && OUT16 && !TT;   // per-tile column sums of the stored values (bias gradient)
+        float cs[COLSUM ? CPL : 1] = {};
         if (HAS_EXTRA) load_extra(0, 0);
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
                     if (EPI == EPI_RESADD) x = extra[mt & 1][i][e] + x;
                     if (EPI == EPI_DGELU) x *= extra[mt & 1][i][e];
                     v[i][e] = x;
+                    if constexpr (COLSUM) cs[e] += grow < p.M ? x : 0.f;
                 }
                 if constexpr (OUT16) {
                     uint4 h, ha;
@@ -410,6 +413,23 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
                     }
                 } else {
                     if (grow < p.M) *(f32x4*)((float*)Cbase + o) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+                }
+            }
+        }
+        if constexpr (COLSUM) {
+            if (p.colsum_scratch) {   // the 8 row lanes of a column group (lane >> 3) combine; partial row = (row tile, wave row)
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) {
+                    float t = cs[e];
+                    t += __shfl_xor(t, 8, 64);
+                    t += __shfl_xor(t, 16, 64);
+                    t += __shfl_xor(t, 32, 64);
+                    cs[e] = t;
+                }
+                if (rrow == 0) {
+                    float* dst = p.colsum_scratch + (size_t)((tc.m0 / PT) * 2 + wr) * p.N + gcol;
+                    *(f32x4*)dst = f32x4{cs[0], cs[1], cs[2], cs[3]};
+                    *(f32x4*)(dst + 4) = f32x4{cs[CPL - 4], cs[CPL - 3], cs[CPL - 2], cs[CPL - 1]};
                 }
             }
         }

@@ -31,6 +31,12 @@ struct GemmArgs {
     int lda, ldc;
     int ldw;            // leading dimension of W (0 = dense: K for N-form, N for T-form)
     void* aux;          // EPI_GELU: optional second output, the pre-activation (saved for backward)
+    // EPI_DGELU (16-bit): also produce the column sums of the output rows (the bias gradient of the layer whose
+    // pre-activation gradient C is) without re-reading C: the 8-phase kernel writes per-tile partial sums to
+    // colsum_scratch (colsum_scratch_floats(M, N) floats), the dispatcher adds the rows that kernel did not cover and
+    // reduces in a fixed order into colsum_out[N]
+    float* colsum_out;
+    float* colsum_scratch;
     // geometry for A_PATCH / A_CONV3 / EPI_POS
     int S, P, g, Np, Cin, D;
     const void* zeros;  // >= 128 zero bytes (bf16 A_CONV3: source of the padding taps)
@@ -123,6 +129,8 @@ int launch_dropout_rows(const float* src, void* dst, int dst_bf16, int rows, int
 
 // ---- backward pass (backward.hip) ----
 size_t colsum_scratch_floats(int M, int N);
+int launch_colsum_finish_fused(const void* tail_rows, int tail, int chunk0, float* out, float* scratch, int N, int ld,
+                               hipStream_t s);
 int launch_colsum(const void* X, int x_is_bf16, float* out, float* scratch, int M, int N, int ld, hipStream_t s);
 int launch_transpose_bf16(const void* in, void* out, int R, int C, int ldin, int Rpad, hipStream_t s);
 size_t layernorm_bwd_scratch_floats(int rows, int D);

@@ -353,7 +353,8 @@ int vitseg_op_linear_f16(const void* A, const void* Wt, const float* bias, const
 
 int vitseg_op_linear_h16_ex(const void* A, const void* Wt, const float* bias, const void* R, void* C, void* aux, int M,
                             int N, int K, int epilogue, int f16, int thin_rows, float* scratch, size_t scratch_floats,
-                            float dropout_p, uint32_t dropout_seed, uint32_t dropout_stream, void* stream) {
+                            float dropout_p, uint32_t dropout_seed, uint32_t dropout_stream, float* colsum_out,
+                            float* colsum_scratch, void* stream) {
     VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "linear_h16_ex: null pointer");
     VITSEG_CHECK_ARG(epilogue == EPI_BIAS || epilogue == EPI_GELU || epilogue == EPI_RESADD || epilogue == EPI_DGELU,
                      VITSEG_EINVAL, "linear_h16_ex: epilogue %d", epilogue);
@@ -374,8 +375,14 @@ int vitseg_op_linear_h16_ex(const void* A, const void* Wt, const float* bias, co
         g.drop.stream = dropout_stream;
         g.drop.scale = 1.0f / (1.0f - dropout_p);
     }
+    VITSEG_CHECK_ARG(!colsum_out || (colsum_scratch && epilogue == EPI_DGELU && !f16), VITSEG_EINVAL,
+                     "linear_h16_ex: column sums come with the bf16 dGELU epilogue and need scratch");
+    g.colsum_out = colsum_out;
+    g.colsum_scratch = colsum_out ? colsum_scratch : nullptr;
     return launch_gemm_bf16(g, A_PLAIN, epilogue, (hipStream_t)stream, f16 != 0);
 }
+
+size_t vitseg_op_colsum_scratch_floats(int M, int N) { return colsum_scratch_floats(M, N); }
 
 size_t vitseg_op_wgrad_bf16_scratch_floats(int M, int N, int K) { return wgrad_bf16_scratch_floats(M, N, K); }
 

@@ -307,7 +307,10 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
     };
     (void)Kpad;
     // dX[Mt,Kd] = dY[Mt,Nd] . W[Nd,Kd]  with W^T materialised as [Kd][Nd] bf16
-    auto dgrad = [&](const void* dY, const unsigned short* Wlp, void* dX, int Nd, int Kd, int epi, const void* R) {
+    // bias_grad (EPI_DGELU): the column sums of dX -- the bias gradient of the layer dX is the pre-activation gradient of --
+    // come out of the GEMM epilogue (GemmArgs::colsum_*) instead of a pass over dX
+    auto dgrad = [&](const void* dY, const unsigned short* Wlp, void* dX, int Nd, int Kd, int epi, const void* R,
+                     float* bias_grad = nullptr) {
         int r;
         ProfScope ps(VITSEG_K_TRAIN_DGRAD, 2.0 * Mt * Nd * Kd, st);
         if ((r = launch_transpose_bf16(Wlp, wT, Nd, Kd, Kd, Nd, st))) return r;
@@ -318,6 +321,8 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
             g.thin_scratch = wscr;                   // the weight-gradient partial buffer is idle here
             g.thin_capacity = c.p.wscratch_floats;
         }
+        g.colsum_out = bias_grad;
+        g.colsum_scratch = bias_grad ? scratch : nullptr;
         return launch_gemm_bf16_train(g, epi, 0, nullptr, st);
     };
 
@@ -382,8 +387,7 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
             if ((rc = launch_colsum(dXc, 1, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
         }
         if ((rc = wgrad(dXc, c.LV(l, c.p.lb.uact), G(VITSEG_T_W2, l), D, I))) return rc;
-        if ((rc = dgrad(dXc, c.WL(VITSEG_T_W2, l), dU, D, I, EPI_DGELU, c.LV(l, c.p.lb.upre)))) return rc;
-        if ((rc = launch_colsum(dU, 1, G(VITSEG_T_B1, l), scratch, Mt, I, I, st))) return rc;
+        if ((rc = dgrad(dXc, c.WL(VITSEG_T_W2, l), dU, D, I, EPI_DGELU, c.LV(l, c.p.lb.upre), G(VITSEG_T_B1, l)))) return rc;
         if ((rc = wgrad(dU, c.LV(l, c.p.lb.h2), G(VITSEG_T_W1, l), I, D))) return rc;
         if ((rc = dgrad(dU, c.WL(VITSEG_T_W1, l), dH, I, D, EPI_BIAS, nullptr))) return rc;
         if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xmid), c.W(VITSEG_T_LN2_W, l), dH, 1, dXa, dXb, G(VITSEG_T_LN2_W, l),
