@@ -437,6 +437,37 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     }
 }
 
+// All dgrad operands of a training step in ONE launch: the four weight matrices of every encoder layer, [R][C] bf16 in
+// the shadow arena -> [C][R] (48 small transposes between the big GEMMs cost ~10 us each of mostly launch latency).
+// blockIdx.z = 4 * layer + kind; the grid covers the largest matrix, smaller ones leave early.
+struct TransposeBatch {
+    size_t src0[4], dst0[4];   // element offsets of layer 0's matrices in the shadow arena / in the output
+    int R[4], C[4];
+    size_t src_stride, dst_stride;   // per layer
+};
+__global__ __launch_bounds__(256) void transpose_layers_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                                    TransposeBatch tb) {
+    __shared__ bf16_t tile[64][66];
+    const int kind = blockIdx.z & 3, layer = blockIdx.z >> 2;
+    const int R = tb.R[kind], C = tb.C[kind];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    if (r0 >= R || c0 >= C) return;   // block-uniform
+    const bf16_t* src = in + tb.src0[kind] + (size_t)layer * tb.src_stride;
+    bf16_t* dst = out + tb.dst0[kind] + (size_t)layer * tb.dst_stride;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + i * 4 + ty, c = c0 + tx;
+        tile[i * 4 + ty][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : (bf16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + i * 4 + ty, r = r0 + tx;
+        if (c < C && r < R) dst[(size_t)c * R + r] = tile[tx][i * 4 + ty];
+    }
+}
+
 inline int grid_for(size_t n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
 
 }  // namespace
@@ -470,6 +501,28 @@ int launch_colsum(const void* X, int x_is_bf16, float* out, float* scratch, int 
     VITSEG_LAUNCH_CHECK("colsum_partial");
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, scratch, out, chunks, N);
     VITSEG_LAUNCH_CHECK("colsum_finish");
+    return VITSEG_OK;
+}
+
+int launch_transpose_layers_bf16(const void* arena_lp, void* out, const size_t src0[4], const int R[4], const int C[4],
+                                 size_t src_stride, int layers, hipStream_t s) {
+    TransposeBatch tb{};
+    size_t off = 0;
+    int maxR = 0, maxC = 0;
+    for (int k = 0; k < 4; ++k) {
+        tb.src0[k] = src0[k];
+        tb.dst0[k] = off;
+        tb.R[k] = R[k];
+        tb.C[k] = C[k];
+        off += (size_t)R[k] * C[k];
+        maxR = R[k] > maxR ? R[k] : maxR;
+        maxC = C[k] > maxC ? C[k] : maxC;
+    }
+    tb.src_stride = src_stride;
+    tb.dst_stride = off;
+    hipLaunchKernelGGL(transpose_layers_bf16_kernel, dim3((maxC + 63) / 64, (maxR + 63) / 64, 4 * layers), dim3(256), 0, s,
+                       (const bf16_t*)arena_lp, (bf16_t*)out, tb);
+    VITSEG_LAUNCH_CHECK("transpose_layers_bf16");
     return VITSEG_OK;
 }
 

@@ -132,6 +132,10 @@ size_t colsum_scratch_floats(int M, int N);
 int launch_colsum_finish_fused(const void* tail_rows, int tail, int chunk0, float* out, float* scratch, int N, int ld,
                                hipStream_t s);
 int launch_colsum(const void* X, int x_is_bf16, float* out, float* scratch, int M, int N, int ld, hipStream_t s);
+// the four weight matrices (R[k] x C[k], at element offsets src0[k] + layer * src_stride of the 16-bit shadow arena) of
+// every layer, transposed into out[layer][k] (dense, layer stride = sum R C)
+int launch_transpose_layers_bf16(const void* arena_lp, void* out, const size_t src0[4], const int R[4], const int C[4],
+                                 size_t src_stride, int layers, hipStream_t s);
 int launch_transpose_bf16(const void* in, void* out, int R, int C, int ldin, int Rpad, hipStream_t s);
 size_t layernorm_bwd_scratch_floats(int rows, int D);
 int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is_bf16, const float* dres_in,

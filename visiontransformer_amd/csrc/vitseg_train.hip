@@ -27,6 +27,7 @@ struct TrainPlan {
     // bf16 training only: bf16 copy of the fp32 residual gradient, transposed weight for dgrad, zero page,
     // fp32 gradient of the final LayerNorm output
     size_t dxc, wt, zero, dhf, Kpad;
+    size_t wt_all, wt_layer;  // every layer's four weights transposed (dgrad operands), elements per layer
     size_t dxm;  // fp32 path with dropout: masked copy of the residual gradient that enters a dropped branch
 };
 
@@ -100,6 +101,8 @@ TrainPlan make_train_plan(const Shape& s, int B, int precision) {
         p.dxc = take(p.Mt * s.D * 2);
         p.dhf = take(p.Mp * s.D * 4);
         p.wt = take(wide * s.D * 2);
+        p.wt_layer = (size_t)s.D * (3 * s.D + s.D + 2 * (size_t)s.I);
+        p.wt_all = take(p.wt_layer * s.L * 2);
         p.zero = take(256);
         size_t w = wgrad_bf16_scratch_floats(s.D, s.I, (int)p.Kpad);
         auto mx = [&](size_t v) { w = v > w ? v : w; };
@@ -309,12 +312,23 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
     // dX[Mt,Kd] = dY[Mt,Nd] . W[Nd,Kd]  with W^T materialised as [Kd][Nd] bf16
     // bias_grad (EPI_DGELU): the column sums of dX -- the bias gradient of the layer dX is the pre-activation gradient of --
     // come out of the GEMM epilogue (GemmArgs::colsum_*) instead of a pass over dX
-    auto dgrad = [&](const void* dY, const unsigned short* Wlp, void* dX, int Nd, int Kd, int epi, const void* R,
+    // dgrad operands: W^T of the four linears of every layer, materialised by ONE launch (order: QKV, O, fc1, fc2)
+    const size_t wt_off[4] = {0, (size_t)3 * D * D, (size_t)4 * D * D, (size_t)4 * D * D + (size_t)I * D};
+    {
+        const size_t src0[4] = {tensor_offset(c.lay, VITSEG_T_WQKV, 0), tensor_offset(c.lay, VITSEG_T_WO, 0),
+                                tensor_offset(c.lay, VITSEG_T_W1, 0), tensor_offset(c.lay, VITSEG_T_W2, 0)};
+        const int R4[4] = {3 * D, D, I, D}, C4[4] = {D, D, D, I};
+        const size_t lstride = c.lay.layer_stride;
+        ProfScope ps(VITSEG_K_TRAIN_DGRAD, 0.0, st);
+        if ((rc = launch_transpose_layers_bf16(c.params_lp, c.TV(c.p.wt_all), src0, R4, C4, lstride, s.L, st))) return rc;
+    }
+    auto wT_of = [&](int l, int kind) {
+        return (const void*)((const unsigned short*)c.TV(c.p.wt_all) + (size_t)l * c.p.wt_layer + wt_off[kind]);
+    };
+    auto dgrad = [&](const void* dY, const void* Wt, void* dX, int Nd, int Kd, int epi, const void* R,
                      float* bias_grad = nullptr) {
-        int r;
         ProfScope ps(VITSEG_K_TRAIN_DGRAD, 2.0 * Mt * Nd * Kd, st);
-        if ((r = launch_transpose_bf16(Wlp, wT, Nd, Kd, Kd, Nd, st))) return r;
-        GemmArgs g = lin(dY, wT, nullptr, (const float*)R, dX, Mt, Kd, Nd, Nd, Kd);
+        GemmArgs g = lin(dY, Wt, nullptr, (const float*)R, dX, Mt, Kd, Nd, Nd, Kd);
         g.ldw = Nd;
         if (Mp % 256 == 0 && B <= THIN_MAX_ROWS) {  // CLS rows as a split-K side launch (whole-tile body, see GemmArgs)
             g.thin_rows = B;
@@ -387,14 +401,14 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
             if ((rc = launch_colsum(dXc, 1, G(VITSEG_T_B2, l), scratch, Mt, D, D, st))) return rc;
         }
         if ((rc = wgrad(dXc, c.LV(l, c.p.lb.uact), G(VITSEG_T_W2, l), D, I))) return rc;
-        if ((rc = dgrad(dXc, c.WL(VITSEG_T_W2, l), dU, D, I, EPI_DGELU, c.LV(l, c.p.lb.upre), G(VITSEG_T_B1, l)))) return rc;
+        if ((rc = dgrad(dXc, wT_of(l, 3), dU, D, I, EPI_DGELU, c.LV(l, c.p.lb.upre), G(VITSEG_T_B1, l)))) return rc;
         if ((rc = wgrad(dU, c.LV(l, c.p.lb.h2), G(VITSEG_T_W1, l), I, D))) return rc;
-        if ((rc = dgrad(dU, c.WL(VITSEG_T_W1, l), dH, I, D, EPI_BIAS, nullptr))) return rc;
+        if ((rc = dgrad(dU, wT_of(l, 2), dH, I, D, EPI_BIAS, nullptr))) return rc;
         if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xmid), c.W(VITSEG_T_LN2_W, l), dH, 1, dXa, dXb, G(VITSEG_T_LN2_W, l),
                                        G(VITSEG_T_LN2_B, l), scratch, Mt, D, c.eps, st, dXc, c.dr(l, 2), G(VITSEG_T_BO, l))))
             return rc;
         if ((rc = wgrad(dXc, c.LV(l, c.p.lb.ctx), G(VITSEG_T_WO, l), D, D))) return rc;
-        if ((rc = dgrad(dXc, c.WL(VITSEG_T_WO, l), dCTX, D, D, EPI_BIAS, nullptr))) return rc;
+        if ((rc = dgrad(dXc, wT_of(l, 1), dCTX, D, D, EPI_BIAS, nullptr))) return rc;
         {
             ProfScope ps(VITSEG_K_TRAIN_ATTN_BWD, attn_flops(c, 10), st);
             if ((rc = launch_attention_bwd_bf16(c.LV(l, c.p.lb.qkv), c.LV(l, c.p.lb.ctx), dCTX, c.L(l, c.p.lb.lse),
@@ -403,7 +417,7 @@ int backward_bf16(Ctx& c, const float* x, const void* target, int target_is_u8, 
         }
         if ((rc = launch_colsum(dQKV, 1, G(VITSEG_T_BQKV, l), scratch, Mt, 3 * D, 3 * D, st))) return rc;
         if ((rc = wgrad(dQKV, c.LV(l, c.p.lb.h1), G(VITSEG_T_WQKV, l), 3 * D, D))) return rc;
-        if ((rc = dgrad(dQKV, c.WL(VITSEG_T_WQKV, l), dH, 3 * D, D, EPI_BIAS, nullptr))) return rc;
+        if ((rc = dgrad(dQKV, wT_of(l, 0), dH, 3 * D, D, EPI_BIAS, nullptr))) return rc;
         if (l > 0) {  // next branch of the walk: layer l-1's MLP output
             if ((rc = launch_layernorm_bwd(c.L(l, c.p.lb.xin), c.W(VITSEG_T_LN1_W, l), dH, 1, dXb, dXa, G(VITSEG_T_LN1_W, l),
                                            G(VITSEG_T_LN1_B, l), scratch, Mt, D, c.eps, st, dXc, c.dr(l - 1, 3),
