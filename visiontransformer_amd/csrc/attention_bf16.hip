@@ -30,10 +30,11 @@ __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 
 
 // H: format tag of the 16-bit storage (bf16_t or f16_t, common.hpp H16<>); pointers are raw 16-bit words.
 // DROP: attention-probability dropout compiled in (training); RAGGED: Np is not a multiple of the 128-query block.
-// Online softmax with a DEFERRED maximum: the S accumulators start at -m (the running maximum, raw score units), so
-// p = exp2(c * acc) with no subtraction; m only moves -- and O, l are only rescaled -- when some score exceeds it by more
-// than 8 / c, i.e. p > 2^8 (wave-uniform, rare after the first tiles): P stays <= 256, exact in the fp32 sums and harmless
-// in the 16-bit P.  (Prescaling q by c instead would save the multiply too, but a second rounding of q to the 16-bit
+// Online softmax with a DEFERRED maximum: p = exp2(fma(s, c, -c m)) with the running maximum m (raw score units) in the
+// fma's addend -- one VALU op per score, accumulators started from the MFMA's zero constant; m only moves -- and O, l are
+// only rescaled -- when some score exceeds it by more than 8 / c, i.e. p > 2^8 (wave-uniform, rare after the first tiles):
+// P stays <= 256, exact in the fp32 sums and harmless in the 16-bit P.  (MFMA and fp32 VALU cycles add up on a SIMD --
+// DESIGN.md section 3 -- so every op per score counts.)  (Prescaling q by c instead would save the multiply too, but a second rounding of q to the 16-bit
 // format costs accuracy on peaked rows: measured 0.041 vs 0.03 max error in the op test; it belongs into the QKV
 // projection's epilogue, before the first rounding.)
 // MW (with DROP, without RAGGED): the keep bits come as precomputed words (common.hpp attn_dropmask_words): the lane mask
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = -m_run;
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;   // inline-constant C operand of the first MFMA: no moves
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f32x4 kf = *(const f32x4*)&Ks[kb * 32 * HD + k_off + (((2 * s + lh) ^ k_sw) << 3)];
@@ -180,28 +181,25 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // the running maximum settles after the first few key tiles: m, O and l move only when some lane's scores
         // exceed it by more than the threshold (wave-uniform branch)
-        if (__builtin_amdgcn_ballot_w64(mx > DEFER_THR * (1.0f / (0.125f * LOG2E))) != 0) {
-            const float delta = fmaxf(mx, 0.f);
+        if (__builtin_amdgcn_ballot_w64(mx - m_run > DEFER_THR * (1.0f / (0.125f * LOG2E))) != 0) {
+            const float delta = fmaxf(mx - m_run, 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-delta * c);
             l_run *= alpha;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[kb][r] -= delta;
             m_run += delta;
         }
+        const float nmc = -m_run * c;   // p = exp2(c s - c m): the running maximum enters through the fma's addend
         float psum = 0.f;
         unsigned pk[2][8];  // P^T fragments: pk[kb][4 s + w] = registers 8 s + 2 w, 8 s + 2 w + 1
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float p0 = __builtin_amdgcn_exp2f(st[kb][r] * c);
-                float p1 = __builtin_amdgcn_exp2f(st[kb][r + 1] * c);
+                float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, nmc));
+                float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c, nmc));
                 psum += p0 + p1;
                 if (MW) {
                     p0 = mask_select(lm.reg(kb, r), p0);
