@@ -138,6 +138,13 @@ int vitseg_op_layernorm_f32(const float* x, const float* w, const float* b, floa
 /* C[M,N] = epi(A[M,K] . W[N,K]^T + bias); epi: 0 none, 1 erf-GELU, 2 + R[M,N] (R may alias C), 3 ReLU */
 int vitseg_op_linear_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
                          int K, int epilogue, void* stream);
+/* the same with the training forms of the fp32 forward: aux (optional, epilogue 1) receives the pre-activation
+ * A.W^T + bias; dropout_p > 0 (epilogue 2): C = R + dropout(A.W^T + bias) with the counter-based mask of
+ * (dropout_seed, dropout_stream, row, column), as vitseg_forward_train applies it (reference: hidden dropout,
+ * transformers/models/vit/modeling_vit.py:276,283). */
+int vitseg_op_linear_f32_ex(const float* A, const float* W, const float* bias, const float* R, float* C, float* aux,
+                            int M, int N, int K, int epilogue, float dropout_p, uint32_t dropout_seed,
+                            uint32_t dropout_stream, void* stream);
 /* qkv: [B*Np + B, 3*A*64] rows as in the workspace; ctx: [B*Np + B, A*64] */
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream);
 /* bf16 operands (A, W as raw bf16 bits), fp32 accumulate; bias and R fp32.  C is bf16 for epilogues 0/1

@@ -60,6 +60,61 @@ def test_linear_epilogues(M, N, K, epi):
     assert err < bound, (err, bound)
 
 
+@pytest.mark.parametrize("M,N,K,epi,extra", [
+    (8192, 768, 768, 2, ""),             # o_proj: whole 256-row tiles, in-place residual
+    (8292, 768, 768, 2, "drop"),         # ragged last row tile (masked stores) + hidden dropout (fp32 training forward)
+    (4096, 2304, 768, 0, ""),            # QKV
+    (4196, 3072, 768, 1, "aux"),         # fc1: GELU + saved pre-activation, ragged
+    (8192, 768, 3072, 2, ""),            # fc2: long K (96 ring steps per tile)
+    (16384, 256, 96, 3, ""),             # ReLU, the minimum of 3 K steps, 2 column tiles
+    (33024, 768, 64 * 5, 0, "nobias"),   # more tiles than CUs x 3: uneven tile counts per block, no bias
+])
+def test_linear_f32_persistent_kernel(M, N, K, epi, extra, monkeypatch):
+    """csrc/gemm_f32p.hip (persistent 256x128 kernel of the fp32 linears) against a float64 product, and BITWISE against
+    gemm.hip's tile kernel (same k order per dot product): modeling_vit.py:207-254."""
+    L = _lib.lib()
+    A, W = _rand(M, K, seed=M), _rand(N, K, seed=N + 1, scale=0.05)
+    bias = None if "nobias" in extra else _rand(N, seed=7, scale=0.1)
+    R = _rand(M, N, seed=11)
+    p, seed, stream_id = (0.1, 0x1234ABCD, 13) if "drop" in extra else (0.0, 0, 0)
+    acc = A.double() @ W.double().T + (bias.double() if bias is not None else 0.0)
+    if epi == 1:
+        ref = O.gelu_erf(acc)
+    elif epi == 2:
+        ref = R.double() + (acc * _drop_rows_np(M, N, p, seed, stream_id).double() if p else acc)
+    elif epi == 3:
+        ref = torch.relu(acc)
+    else:
+        ref = acc
+    Ad, Wd, Rd = A.to(DEV), W.to(DEV), R.to(DEV)
+    bd = bias.to(DEV) if bias is not None else None
+
+    def run():
+        C = torch.full((M, N), float("nan"), device=DEV)
+        aux = torch.full((M, N), float("nan"), device=DEV) if "aux" in extra else None
+        Rp = None
+        if epi == 2:  # in-place residual, as the forward uses it
+            C.copy_(Rd)
+            Rp = C.data_ptr()
+        _lib.check(L.vitseg_op_linear_f32_ex(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr() if bd is not None else None, Rp,
+                                             C.data_ptr(), aux.data_ptr() if aux is not None else None, M, N, K, epi, p,
+                                             seed, stream_id, _stream()))
+        torch.cuda.synchronize()
+        return C, aux
+
+    C, aux = run()
+    monkeypatch.setenv("VITSEG_NO_F32P", "1")
+    C_old, aux_old = run()
+    monkeypatch.delenv("VITSEG_NO_F32P")
+    err = (C.cpu().double() - ref).abs().max().item()
+    bound = 4e-7 * (A.abs().double() @ W.abs().double().T).max().item() * (1.2 if p else 1.0) + 1e-6
+    assert err < bound, (err, bound)
+    assert torch.equal(C, C_old), (C - C_old).abs().max().item()
+    if aux is not None:
+        assert (aux.cpu().double() - acc).abs().max().item() < bound
+        assert torch.equal(aux, aux_old)
+
+
 def test_linear_matches_fp32_fmaf_semantics_exactly_small():
     """A = I (asymmetric W) must come out exactly: catches row/col swaps in the MFMA C layout."""
     M = N = K = 128

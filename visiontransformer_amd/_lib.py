@@ -34,7 +34,7 @@ EXPORTS = [
     "vitseg_resize_nearest_u8", "vitseg_eval_counts", "vitseg_paed_scratch_bytes", "vitseg_paed_multiclass_loss",
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32", "vitseg_op_linear_h16_ex",
     "vitseg_op_wgrad_bf16", "vitseg_op_wgrad_bf16_scratch_floats", "vitseg_op_attention_bwd_bf16", "vitseg_attention_dropmask_bytes", "vitseg_op_colsum_scratch_floats",
-    "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss",
+    "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss", "vitseg_op_linear_f32_ex",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
                 "head1x1", "upsample", "train_gemm_fwd", "train_dgrad", "train_wgrad", "train_attn_fwd", "train_attn_bwd"]
@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
         l.vitseg_forward.argtypes = [pcfg, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]
         l.vitseg_op_layernorm_f32.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp]
         l.vitseg_op_linear_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        l.vitseg_op_linear_f32_ex.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, C.c_uint32, C.c_uint32, vp]
         l.vitseg_op_attention_f32.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_linear_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_bf16.argtypes = [vp, vp, i32, i32, i32, vp]

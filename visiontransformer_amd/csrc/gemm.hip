@@ -813,6 +813,7 @@ int launch_gemm_f32(const GemmArgs& a_in, int amode, int epi, hipStream_t s, int
     }
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 4 == 0, VITSEG_EINVAL, "gemm_f32: lda %% 4");
+        if (gemm_f32p_applies(a, epi)) return launch_gemm_f32p(a, epi, s);   // large shapes: persistent 256x128 kernel
         switch (epi) {
             case EPI_BIAS: return launch_one<float, float, A_PLAIN, EPI_BIAS>(a, s);
             case EPI_GELU: return launch_one<float, float, A_PLAIN, EPI_GELU>(a, s);

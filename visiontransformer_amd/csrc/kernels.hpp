@@ -80,6 +80,9 @@ int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s, bool 
 int gemm_p8_rounds(int M, int N);
 bool gemm_p8_applies(const GemmArgs& a, int epi);
 int launch_gemm_p8(const GemmArgs& a, int epi, hipStream_t s, bool f16);
+// persistent 256x128 fp32 kernel for the large plain linear layers of the parity path (gemm_f32p.hip)
+bool gemm_f32p_applies(const GemmArgs& a, int epi);
+int launch_gemm_f32p(const GemmArgs& a, int epi, hipStream_t s);
 // the same kernel in its T-form x T-form guise (weight gradients, split over the token rows)
 bool wgrad_p8_applies(const GemmArgs& a);
 int wgrad_p8_splits(int M, int N, int K);

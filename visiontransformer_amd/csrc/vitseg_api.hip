@@ -318,6 +318,27 @@ int vitseg_op_linear_f32(const float* A, const float* Wt, const float* bias, con
     return launch_gemm_f32(g, A_PLAIN, epilogue, (hipStream_t)stream);
 }
 
+int vitseg_op_linear_f32_ex(const float* A, const float* Wt, const float* bias, const float* R, float* C, float* aux,
+                            int M, int N, int K, int epilogue, float dropout_p, uint32_t dropout_seed,
+                            uint32_t dropout_stream, void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "linear_f32_ex: null pointer");
+    VITSEG_CHECK_ARG(epilogue >= 0 && epilogue <= 3, VITSEG_EINVAL, "linear_f32_ex: epilogue %d", epilogue);
+    VITSEG_CHECK_ARG(epilogue != EPI_RESADD || R, VITSEG_EINVAL, "linear_f32_ex: residual epilogue needs R");
+    VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "linear_f32_ex: dropout_p %f", dropout_p);
+    VITSEG_CHECK_ARG(!aux || epilogue == EPI_GELU, VITSEG_EINVAL, "linear_f32_ex: aux belongs to the GELU epilogue");
+    GemmArgs g{};
+    g.A = A; g.W = Wt; g.bias = bias; g.R = R; g.C = C; g.aux = aux;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
+    if (dropout_p > 0.f && epilogue == EPI_RESADD) {
+        g.drop.thresh = (unsigned)((double)dropout_p * 65536.0 + 0.5);
+        if (g.drop.thresh == 0) g.drop.thresh = 1;
+        g.drop.seed = dropout_seed;
+        g.drop.stream = dropout_stream;
+        g.drop.scale = 1.0f / (1.0f - dropout_p);
+    }
+    return launch_gemm_f32(g, A_PLAIN, epilogue, (hipStream_t)stream);
+}
+
 int vitseg_op_linear_bf16(const void* A, const void* Wt, const float* bias, const float* R, void* C, int M, int N,
                           int K, int epilogue, void* stream) {
     VITSEG_CHECK_ARG(A && Wt && C, VITSEG_EINVAL, "linear: null pointer");
