@@ -61,13 +61,15 @@ def test_linear_epilogues(M, N, K, epi):
 
 
 @pytest.mark.parametrize("M,N,K,epi,extra", [
-    (8192, 768, 768, 2, ""),             # o_proj: whole 256-row tiles, in-place residual
-    (8292, 768, 768, 2, "drop"),         # ragged last row tile (masked stores) + hidden dropout (fp32 training forward)
-    (4096, 2304, 768, 0, ""),            # QKV
-    (4196, 3072, 768, 1, "aux"),         # fc1: GELU + saved pre-activation, ragged
-    (8192, 768, 3072, 2, ""),            # fc2: long K (96 ring steps per tile)
-    (16384, 256, 96, 3, ""),             # ReLU, the minimum of 3 K steps, 2 column tiles
-    (33024, 768, 64 * 5, 0, "nobias"),   # more tiles than CUs x 3: uneven tile counts per block, no bias
+    (32768, 768, 768, 2, ""),            # o_proj at the bench size: 3 tiles per block, in-place residual, inline epilogue
+    (16484, 768, 256, 2, "drop"),        # ragged last row tile (masked stores) + hidden dropout (fp32 training forward)
+    (12288, 2304, 768, 0, ""),           # QKV: 864 tiles
+    (4196, 3072, 768, 1, "aux"),         # fc1: GELU + saved pre-activation, ragged (epilogue at the tile's end)
+    (16384, 3072, 768, 1, ""),           # fc1: 1 536 tiles
+    (8192, 768, 3072, 2, ""),            # fc2: long K (96 ring steps per tile), one tile per block
+    (16384, 256, 96, 3, ""),             # ReLU, the minimum of 3 K steps (no inline epilogue below 4)
+    (65536, 256, 128, 3, ""),            # ReLU, 4 K steps, 2 tiles per block
+    (33024, 768, 64 * 5, 0, "nobias"),   # uneven tile counts per block, no bias
 ])
 def test_linear_f32_persistent_kernel(M, N, K, epi, extra, monkeypatch):
     """csrc/gemm_f32p.hip (persistent 256x128 kernel of the fp32 linears) against a float64 product, and BITWISE against

@@ -42,7 +42,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define F32P_SB() __builtin_amdgcn_sched_barrier(0)
 
 // DROP: hidden dropout on the residual branch compiled in (fp32 training forward)
-template <int EPI, bool DROP>
+// AUX: the GELU epilogue also stores the pre-activation (fp32 training forward)
+// INL: a finished tile is written under the first K step of the block's next tile (kstep_first; not for GELU, whose
+//      ~36 VALU per element do not fit behind one step's MFMAs)
+template <int EPI, bool DROP, bool AUX, bool INL>
 __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ring | per-wave slabs
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,7 +57,6 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
     const int ntiles = tiles_m * tiles_n;
     const int KT = p.K / FK;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int total_k = my_tiles * KT;
     // Tile order: column groups of `gn` tiles, row panels marching inside a group; the 32 blocks of one XCD
     // (blockIdx % 8 equal) take 32 consecutive items of every round, so an A panel slice is fetched into that L2 once
     // per group and the group's W panels stay there.
@@ -163,12 +165,37 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][nt][e], fa[slot][mt][e], acc[mt][nt], 0, 0, 0);
     };
 
-    // ---- epilogue of one tile ----
+    // ---- epilogue ----
     float* slab = (float*)(lds + RING_BYTES + wave * SLAB_BYTES);
-    // GUARD: the tile hangs over the last row of C (stores are masked per row); whole tiles store unconditionally
+    const int rrow = lane >> 3, c8 = lane & 7;
+    // park a 32 x 32 sub-tile: row li, chunk 2 q + lh at position ^ (li & 7) (conflict-free both ways), re-read row-wise:
+    // lane -> rows 8 ps + rrow, columns 4 c8 .. + 3.  LDS operations of one wave execute in order, so the slab needs
+    // no waits beyond the data dependences.
+    auto park = [&](const f32x16& t, f32x4 (&v)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(f32x4*)(slab + li * 32 + (((2 * q + lh) ^ (li & 7)) << 2)) = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = 8 * ps + rrow;
+            v[ps] = *(const f32x4*)(slab + row * 32 + ((c8 ^ (row & 7)) << 2));
+        }
+    };
+    // one output value: x = accumulator + bias -> the epilogue's function of it (the residual is added by the caller)
+    auto epi_value = [&](float x, float& pre, int grow, int gcol) {
+        if (EPI == EPI_GELU) {
+            pre = x;                            // saved pre-activation (fp32 training)
+            x = gelu_erf(x);
+        }
+        if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
+        if (EPI == EPI_RESADD && DROP)
+            x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow + p.row_base), gcol, p.drop.thresh) ? x * p.drop.scale : 0.f;
+        return x;
+    };
+    // Immediate form (whole tile at once, nothing overlapped): the block's last tile, tiles that hang over the last row
+    // of C (GUARD: stores masked per row), and every tile of the GELU kernels.
     auto epilogue = [&](int m0, int n0, auto guard_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value;
-        const int rrow = lane >> 3, c8 = lane & 7;
         const int gcol0 = n0 + wc * 64 + c8 * 4;
         f32x4 bias4[2];
 #pragma unroll
@@ -183,29 +210,17 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
             const int g = row_of(mt, ps);
             return (size_t)(!GUARD || g < p.M ? g : 0) * p.ldc + gcol0 + nt * 32;
         };
-        auto load_extra = [&](int buf, int t) {
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) extra[buf][ps] = *(const f32x4*)(p.R + off_of(t >> 1, t & 1, ps));
-        };
         if (HAS_R) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) load_extra(t, t);
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) extra[t][ps] = *(const f32x4*)(p.R + off_of(t >> 1, t & 1, ps));
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int mt = t >> 1, nt = t & 1;
-            // park the 32 x 32 sub-tile: row li, chunk 2 q + lh at position ^ (li & 7) (conflict-free both ways);
-            // LDS operations of one wave execute in order, so the slab needs no waits beyond the data dependences
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *(f32x4*)(slab + li * 32 + (((2 * q + lh) ^ (li & 7)) << 2)) =
-                    f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
             f32x4 v[4];
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int row = 8 * ps + rrow;
-                v[ps] = *(const f32x4*)(slab + row * 32 + ((c8 ^ (row & 7)) << 2));
-            }
+            park(acc[mt][nt], v);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int grow = row_of(mt, ps);
@@ -213,20 +228,14 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
                 f32x4 pre = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float x = v[ps][e] + bias4[nt][e];
-                    if (EPI == EPI_GELU) {
-                        pre[e] = x;                       // saved pre-activation (fp32 training)
-                        x = gelu_erf(x);
-                    }
-                    if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
-                    if (EPI == EPI_RESADD && DROP)
-                        x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow + p.row_base), gcol0 + nt * 32 + e,
-                                      p.drop.thresh) ? x * p.drop.scale : 0.f;
+                    float pre_e = 0.f;
+                    float x = epi_value(v[ps][e] + bias4[nt][e], pre_e, grow, gcol0 + nt * 32 + e);
+                    pre[e] = pre_e;
                     if (EPI == EPI_RESADD) x = extra[t][ps][e] + x;
                     v[ps][e] = x;
                 }
                 if (!GUARD || grow < p.M) {
-                    if (EPI == EPI_GELU && p.aux) *(f32x4*)((float*)p.aux + o) = pre;
+                    if (EPI == EPI_GELU && AUX) *(f32x4*)((float*)p.aux + o) = pre;
                     *(f32x4*)((float*)p.C + o) = v[ps];
                 }
             }
@@ -256,62 +265,49 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
 
     int roff = 0;                          // ring offset of the step being computed
     unsigned doff = 2 * STAGE_BYTES;       // ring offset the DMA of step G + 2 goes to
-    int kt_in_tile = 0, tile_seq = 0;
-    for (int G = 0; G < total_k; ++G) {
+    auto rotate_ring = [&]() {
+        roff = roff + STAGE_BYTES == RING_BYTES ? 0 : roff + STAGE_BYTES;
+        doff = doff + STAGE_BYTES == RING_BYTES ? 0 : doff + STAGE_BYTES;
+    };
+    // One K step = 4 groups of 32 MFMAs (one 16-byte chunk pair each).  NB: the step opens with the bias loads of the
+    // tile it belongs to (inline asm, covered by this step's own vmcnt(12) wait; see kstep_first).
+    f32x4 nb0 = {0.f, 0.f, 0.f, 0.f}, nb1 = {0.f, 0.f, 0.f, 0.f};   // bias of the tile being computed (this lane's columns)
+    auto kstep = [&](auto nb_tag, int n0) {
+        constexpr bool NB = decltype(nb_tag)::value;
         const int nroff = roff + STAGE_BYTES == RING_BYTES ? 0 : roff + STAGE_BYTES;
         const unsigned dbase = lds_base + doff;
-        // group 0 (fragments of chunk pair 0 in slot 0)
-        read_frags(roff, 1, 1);
+        if (NB) {
+            const float* bp = p.bias + n0 + wc * 64;
+            const unsigned bo = (unsigned)(c8 * 16);
+            asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:128"
+                         : "=&v"(nb0), "=&v"(nb1) : "v"(bo), "s"(bp) : "memory");
+        }
+#define F32P_GROUP(slot, jn, D0, D1, D2, D3)                                    \
+        read_frags(roff, jn, (slot) ^ 1);                                       \
+        F32P_SB();                                                              \
+        mfma8(slot, 0);                                                         \
+        F32P_SB();                                                              \
+        D0; D1;                                                                 \
+        F32P_SB();                                                              \
+        mfma8(slot, 1);                                                         \
+        F32P_SB();                                                              \
+        D2; D3;                                                                 \
+        F32P_SB();                                                              \
+        mfma8(slot, 2);                                                         \
+        mfma8(slot, 3);                                                         \
         F32P_SB();
-        mfma8(0, 0);
-        F32P_SB();
-        dma_a(dbase, 0);
-        dma_a(dbase, 1);
-        F32P_SB();
-        mfma8(0, 1);
-        F32P_SB();
-        dma_a(dbase, 2);
-        dma_a(dbase, 3);
-        F32P_SB();
-        mfma8(0, 2);
-        mfma8(0, 3);
-        F32P_SB();
-        // group 1
-        read_frags(roff, 2, 0);
-        F32P_SB();
-        mfma8(1, 0);
-        F32P_SB();
-        dma_a(dbase, 4);
-        dma_a(dbase, 5);
-        F32P_SB();
-        mfma8(1, 1);
-        F32P_SB();
-        dma_a(dbase, 6);
-        dma_a(dbase, 7);
-        F32P_SB();
-        mfma8(1, 2);
-        mfma8(1, 3);
-        F32P_SB();
-        // group 2
-        read_frags(roff, 3, 1);
-        F32P_SB();
-        mfma8(0, 0);
-        F32P_SB();
-        dma_w(dbase, 0);
-        dma_w(dbase, 1);
-        F32P_SB();
-        mfma8(0, 1);
-        F32P_SB();
-        dma_w(dbase, 2);
-        dma_w(dbase, 3);
-        F32P_SB();
-        mfma8(0, 2);
-        mfma8(0, 3);
+        F32P_GROUP(0, 1, dma_a(dbase, 0), dma_a(dbase, 1), dma_a(dbase, 2), dma_a(dbase, 3))
+        F32P_GROUP(1, 2, dma_a(dbase, 4), dma_a(dbase, 5), dma_a(dbase, 6), dma_a(dbase, 7))
+        F32P_GROUP(0, 3, dma_w(dbase, 0), dma_w(dbase, 1), dma_w(dbase, 2), dma_w(dbase, 3))
+#undef F32P_GROUP
         advance();
         F32P_SB();
         // group 3: step G + 1 has landed for this wave (its 12 pieces are older than the 12 just issued) and, behind
         // the barrier, for every wave; every wave's reads of stage `roff` precede the barrier too
-        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        if (NB)
+            asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" : "+v"(nb0), "+v"(nb1) :: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         F32P_SB();
         read_frags(nroff, 0, 0);
@@ -321,15 +317,127 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
         mfma8(1, 2);
         mfma8(1, 3);
         F32P_SB();
-        roff = nroff;
-        doff = doff + STAGE_BYTES == RING_BYTES ? 0 : doff + STAGE_BYTES;
-        if (++kt_in_tile == KT) {
-            int m0, n0;
-            coord(tile_seq, m0, n0);
+        rotate_ring();
+    };
+
+    // First K step of a tile when the block's PREVIOUS tile is still in the accumulators (INL kernels: every epilogue
+    // but GELU).  The MFMAs run sub-tile by sub-tile -- 16 in a row on one accumulator (a dependent fp32 MFMA chain
+    // issues at full rate), the first with C = 0 -- so sub-tile t of the finished tile can be parked, finished and
+    // stored right before its accumulator is reused: the epilogue costs no registers, no zeroing pass and hides behind
+    // the step's 128 MFMAs.  The k order of every accumulator is that of the plain step, so results do not change.
+    // Residual rows come through inline-asm loads one sub-tile ahead with hand-counted waits (a compiler-tracked load is
+    // waited for with a count that ignores the DMA pieces issued behind it: thousands of cycles).
+    f32x4 pb0 = {0.f, 0.f, 0.f, 0.f}, pb1 = {0.f, 0.f, 0.f, 0.f};   // bias of the pending tile
+    int pm0 = 0, pn0 = 0;
+    const unsigned rl0 = (unsigned)((rrow * p.ldc + c8 * 4) * 4);     // this lane's piece of row group 0 of a sub-tile
+    const unsigned rstep = (unsigned)(8 * p.ldc * 4);                 // + row group
+    auto kstep_first = [&]() {
+        const int nroff = roff + STAGE_BYTES == RING_BYTES ? 0 : roff + STAGE_BYTES;
+        const unsigned dbase = lds_base + doff;
+        f32x4 ga[2][4], gw[2][4];   // [buffer][chunk pair]: the sub-tile's activation rows / weight rows
+        auto read_sub = [&](int t, int buf) {
+            const int ab = roff + wr * 16384 + (t >> 1) * 4096, wb = roff + A_BYTES + wc * 8192 + (t & 1) * 4096;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ga[buf][j] = *(const f32x4*)(lds + ab + offj[j]);
+                gw[buf][j] = *(const f32x4*)(lds + wb + offj[j]);
+            }
+        };
+        f32x4 rv[2][4];
+        auto load_r = [&](int t, int buf) {
+            const float* rb = p.R + (size_t)(pm0 + wr * 128 + (t >> 1) * 32) * p.ldc + pn0 + wc * 64 + (t & 1) * 32;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rv[buf][ps]) : "v"(rl0 + ps * rstep), "s"(rb) : "memory");
+        };
+        read_sub(0, 0);
+        if (EPI == EPI_RESADD) load_r(0, 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int mt = t >> 1, nt = t & 1, buf = t & 1;
+            if (t < 7) read_sub(t + 1, buf ^ 1);
+            if (EPI == EPI_RESADD && t < 7) load_r(t + 1, buf ^ 1);
+            f32x4 sv[4];
+            park(acc[mt][nt], sv);
+            if (t == 7) {
+                // the rotated barrier of the plain step, before the last sub-tile: every wave has read stage `roff` (the
+                // fragments of sub-tile 7 are in registers) and step G + 1 has landed (RESADD: the vmcnt(4) below ran)
+                if (EPI == EPI_RESADD)
+                    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(rv[1][0]), "+v"(rv[1][1]), "+v"(rv[1][2]), "+v"(rv[1][3]) :: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");   // 12 DMA + 28 stores issued by this step
+                __builtin_amdgcn_s_barrier();
+                F32P_SB();
+                read_frags(nroff, 0, 0);
+            }
+            F32P_SB();
+            // the sub-tile's 16 MFMAs, DMA pieces of step G + 2 in the middle (2 per sub-tile, sub-tiles 0..5)
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 c = zero;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(gw[buf][j][e], ga[buf][j][e], c, 0, 0, 0);
+            F32P_SB();
+            if (t < 4) {
+                dma_a(dbase, 2 * t);
+                dma_a(dbase, 2 * t + 1);
+            } else if (t < 6) {
+                dma_w(dbase, 2 * (t - 4));
+                dma_w(dbase, 2 * (t - 4) + 1);
+            }
+            F32P_SB();
+#pragma unroll
+            for (int j = 2; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(gw[buf][j][e], ga[buf][j][e], c, 0, 0, 0);
+            acc[mt][nt] = c;
+            // finish and store the parked sub-tile of the previous tile (VALU + 4 stores under the MFMAs above)
+            const int row0 = pm0 + wr * 128 + mt * 32, col0 = pn0 + wc * 64 + nt * 32;
+            if (EPI == EPI_RESADD && t < 7) {
+                // R(t) is older than: DMA of sub-tile t - 1 (2), stores of t - 1 (4), R(t + 1) (4), DMA of t (2)
+                if (t == 0)
+                    asm volatile("s_waitcnt vmcnt(6)" : "+v"(rv[buf][0]), "+v"(rv[buf][1]), "+v"(rv[buf][2]), "+v"(rv[buf][3]) :: "memory");
+                else if (t < 6)
+                    asm volatile("s_waitcnt vmcnt(12)" : "+v"(rv[buf][0]), "+v"(rv[buf][1]), "+v"(rv[buf][2]), "+v"(rv[buf][3]) :: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(10)" : "+v"(rv[buf][0]), "+v"(rv[buf][1]), "+v"(rv[buf][2]), "+v"(rv[buf][3]) :: "memory");
+            }
+            char* cb = (char*)((float*)p.C + (size_t)row0 * p.ldc + col0);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pre = 0.f;
+                    float x = epi_value(sv[ps][e] + (nt ? pb1[e] : pb0[e]), pre, row0 + 8 * ps + rrow, col0 + c8 * 4 + e);
+                    if (EPI == EPI_RESADD) x = rv[buf][ps][e] + x;
+                    sv[ps][e] = x;
+                }
+                *(f32x4*)(cb + rl0 + ps * rstep) = sv[ps];
+            }
+            F32P_SB();
+        }
+        advance();
+        rotate_ring();
+    };
+
+    bool pending = false;
+    for (int ts = 0; ts < my_tiles; ++ts) {
+        int m0, n0;
+        coord(ts, m0, n0);
+        if (pending) kstep_first(); else kstep(std::false_type{}, 0);
+        if (INL && p.bias) kstep(std::true_type{}, n0); else kstep(std::false_type{}, 0);
+        for (int kt = 2; kt < KT; ++kt) kstep(std::false_type{}, 0);
+        if (INL && m0 + FM <= p.M && ts + 1 < my_tiles) {
+            pending = true;          // written under the first K step of the block's next tile
+            pm0 = m0;
+            pn0 = n0;
+            pb0 = nb0;
+            pb1 = nb1;
+        } else {
+            pending = false;
             if (m0 + FM <= p.M) epilogue(m0, n0, std::false_type{}); else epilogue(m0, n0, std::true_type{});
             zero_acc();
-            kt_in_tile = 0;
-            ++tile_seq;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land after the block has left the CU
@@ -348,22 +456,29 @@ int f32p_num_cus() {
     return ncu[dev];
 }
 
-template <int EPI, bool DROP = false>
-int launch_f32p_one(const GemmArgs& a, hipStream_t s) {
+template <int EPI, bool DROP, bool AUX, bool INL>
+int launch_f32p_one_i(const GemmArgs& a, hipStream_t s) {
     int dev = 0;
     static bool attr_set[64] = {};
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32p_kernel<EPI, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32p_kernel<EPI, DROP, AUX, INL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            F32P_LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_f32p)");
         attr_set[dev] = true;
     }
     const int tiles = ((a.M + FM - 1) / FM) * (a.N / FN);
     const int ncu = f32p_num_cus();
-    hipLaunchKernelGGL((gemm_f32p_kernel<EPI, DROP>), dim3(tiles < ncu ? tiles : ncu), dim3(256), F32P_LDS, s, a);
+    hipLaunchKernelGGL((gemm_f32p_kernel<EPI, DROP, AUX, INL>), dim3(tiles < ncu ? tiles : ncu), dim3(256), F32P_LDS, s, a);
     VITSEG_LAUNCH_CHECK("gemm_f32p");
     return VITSEG_OK;
+}
+
+template <int EPI, bool DROP = false, bool AUX = false>
+int launch_f32p_one(const GemmArgs& a, hipStream_t s) {
+    static const bool noinl = getenv("VITSEG_F32P_NOINL") != nullptr;   // experiments: every epilogue at its tile's end
+    if (EPI == EPI_GELU || noinl || a.K < 4 * FK) return launch_f32p_one_i<EPI, DROP, AUX, false>(a, s);
+    return launch_f32p_one_i<EPI, DROP, AUX, EPI != EPI_GELU>(a, s);
 }
 
 }  // namespace
@@ -385,7 +500,7 @@ int launch_gemm_f32p(const GemmArgs& a_in, int epi, hipStream_t s) {
     if (a.ldw == 0) a.ldw = a.K;
     switch (epi) {
         case EPI_BIAS: return launch_f32p_one<EPI_BIAS>(a, s);
-        case EPI_GELU: return launch_f32p_one<EPI_GELU>(a, s);
+        case EPI_GELU: return a.aux ? launch_f32p_one<EPI_GELU, false, true>(a, s) : launch_f32p_one<EPI_GELU>(a, s);
         case EPI_RESADD:
             return a.drop.thresh ? launch_f32p_one<EPI_RESADD, true>(a, s) : launch_f32p_one<EPI_RESADD>(a, s);
         case EPI_RELU: return launch_f32p_one<EPI_RELU>(a, s);
