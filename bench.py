@@ -359,7 +359,8 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
             "config": {"workload": f"ViT-B/16 seg TRAINING step (forward + CE + backward + Adam), batch {B}/GPU x "
                                    f"512x512, {args.precision}, dropout {model.dropout} (reference: 0.1)", "batch_per_gpu": B,
                        "global_batch": B * world,
-                       "parallelism": f"data-parallel x{world}, bucketed gradient all-reduce (RCCL) overlapped with the backward"},
+                       "parallelism": f"data-parallel x{world}, bucketed gradient all-reduce ({collective_name(world)}) "
+                                      f"overlapped with the backward"},
             # dominant kernel group of the step (largest summed device time): algorithmic FLOPs / hipEvent time on the
             # launch stream; per-kernel times of the same command: profiles/r02_bench_train_*_kernel_stats.csv
             "roofline": {"bound": "mfma", "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
@@ -377,12 +378,25 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
     barrier()
 
 
-def self_launch(n):
+def collective_name(world):
+    """What the process group actually runs its all-reduce on (torch's "nccl" backend IS RCCL on ROCm)."""
+    if world <= 1:
+        return "none: single rank"
+    import torch.distributed as dist
+    backend = str(dist.get_backend())
+    return {"nccl": "RCCL over xGMI"}.get(backend, backend)
+
+
+def self_launch(n, child=None):
     """`python bench.py --gpus N` without a launcher: N child processes (one rank per GPU, rendezvous on 127.0.0.1),
     started BEFORE this process makes any HIP call (a process that has initialised the GPU must not exec/fork GPU work).
-    The parent only waits; rank 0's JSON line goes to stdout unchanged.  Returns the worst child exit code."""
+    The parent only waits; rank 0's JSON line goes to stdout unchanged.  Returns the worst child exit code (non-zero as
+    soon as any rank dies; the survivors are killed, none is left behind).  `child`: the command line of one rank
+    (default: this script with this invocation's arguments; tests/test_dist_cpu.py passes a stub that needs no GPU)."""
     import socket
     import subprocess
+    if child is None:
+        child = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -391,8 +405,7 @@ def self_launch(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+        procs.append(subprocess.Popen(list(child), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     try:
         while any(p.poll() is None for p in procs):
@@ -406,6 +419,8 @@ def self_launch(n):
             if p.poll() is None:
                 p.kill()
                 rc = rc or 1
+        for p in procs:
+            p.wait()          # reap: no zombie / orphan outlives the launcher
     return rc
 
 

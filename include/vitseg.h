@@ -246,6 +246,11 @@ int vitseg_preprocess_u8(const uint8_t* img, int n, int H, int W, int S, const i
                          float* out, void* stream);
 int vitseg_resize_nearest_u8(const uint8_t* src, int n, int H, int W, const int32_t* yidx, const int32_t* xidx, int out_h,
                              int out_w, const uint8_t* lut, int out_is_i64, void* out, void* stream);
+/* the same gather for int64 class-index maps (torch.long targets): LightningViTModel._resize_target,
+ * model/CE/classes.py:273-274 = F.interpolate(y[:, None].float(), size, mode='nearest').long() with the mode-1 tables;
+ * writes int64 (the reference's dtype) or uint8 (what vitseg_backward / vitseg_ce_loss read at a quarter of the bytes) */
+int vitseg_resize_nearest_i64(const int64_t* src, int n, int H, int W, const int32_t* yidx, const int32_t* xidx, int out_h,
+                              int out_w, int out_is_i64, void* out, void* stream);
 
 /* ---- soft PAED loss for C classes (replaces softmax + one_hot + paed_loss_multiclass_soft and its autograd in the
  *      17-class LightningViTModel of model/PAED, classes.py:336-369, 449-478).  logits: fp32 [B, C, H, W]; target:

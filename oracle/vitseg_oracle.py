@@ -144,16 +144,19 @@ def encoder(x, sd, cfg, stages=None, drop=None):
 
 
 # ----------------------------------------------------------------------------- a10/a11
-def seg_head(hidden, sd):
+def seg_head(hidden, sd, stages=None):
     """Drop CLS, tokens -> NCHW, Conv3x3(pad 1) + ReLU + Conv1x1.
 
-    model/CE/classes.py:250-257 (glue + seg_head), :240-244 (definition).
+    model/CE/classes.py:250-257 (glue + seg_head), :240-244 (definition).  stages["head_pre"] = the ReLU's input
+    (the tests use it to name the units whose sign an fp32 evaluation can flip).
     """
     B, N, D = hidden.shape
     g = int((N - 1) ** 0.5)
     f = hidden[:, 1:, :].transpose(1, 2).reshape(B, D, g, g)
-    f = torch.relu(torch.nn.functional.conv2d(f, sd["seg_head.0.weight"], sd["seg_head.0.bias"], padding=1))
-    return torch.nn.functional.conv2d(f, sd["seg_head.2.weight"], sd["seg_head.2.bias"])
+    pre = torch.nn.functional.conv2d(f, sd["seg_head.0.weight"], sd["seg_head.0.bias"], padding=1)
+    if stages is not None:
+        stages["head_pre"] = pre
+    return torch.nn.functional.conv2d(torch.relu(pre), sd["seg_head.2.weight"], sd["seg_head.2.bias"])
 
 
 # ----------------------------------------------------------------------------- a12
@@ -218,7 +221,7 @@ def forward(x, sd, cfg, stages=None, drop=None):
         raise ValueError(f"Input image size ({x.shape[2]}*{x.shape[3]}) doesn't match model "
                          f"({cfg.image_size}*{cfg.image_size}).")
     hidden = encoder(x, sd, cfg, stages, drop)
-    z = seg_head(hidden, sd)
+    z = seg_head(hidden, sd, stages)
     if stages is not None:
         stages["lowres_logits"] = z
     return upsample_bilinear(z, x.shape[2:])

@@ -260,3 +260,120 @@ def test_gradient_accumulation_reduces_once_per_optimizer_step_gloo_world2():
     # the overlapped (in-backward) reduce is never taken while an accumulated gradient is pending or inside no_sync():
     # only a step's first micro-batch could use it, and that one runs under no_sync() when it is not also the last
     assert overlap_seen == [False] * 8
+
+
+# ---------------------------------------------------------------- trainer.fit end to end on two ranks
+def _fit_data():
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 4, 64, generator=g), torch.randn(8, 4, generator=g)       # 8 global batches of 4 samples
+    Xv, Yv = torch.randn(2, 4, 64, generator=g), torch.randn(2, 4, generator=g)
+    return X, Y, Xv, Yv
+
+
+def _fit_worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from visiontransformer_amd import trainer
+    X, Y, Xv, Yv = _fit_data()
+    # data parallelism: every global batch of 4 is split into one micro-batch of 2 per rank
+    lo, hi = 2 * rank, 2 * rank + 2
+    train = [(X[i, lo:hi], Y[i, lo:hi]) for i in range(8)]
+    val = [(Xv[i, lo:hi], Yv[i, lo:hi]) for i in range(2)]
+    lm = _StubLightning()
+    rows = trainer.fit(lm, train, val, max_epochs=2, accumulate_grad_batches=2, device="cpu",
+                       ckpt_dir=os.path.join(tmp, "ckpt"), log_dir=os.path.join(tmp, "logs"))
+    if rank == 0:
+        q.put((lm.model.arena.detach().tolist(), [r for r in rows if "valid_loss" in r]))   # plain lists: no shared storage
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_fit_two_epochs_gloo_world2_equals_single_process(tmp_path):
+    """trainer.fit on 2 ranks over gloo -- two epochs, accumulate_grad_batches = 2, validation, checkpoints, metrics.csv --
+    against the SAME fit in one process fed the global batches: identical parameters after 8 optimizer steps, identical
+    validation losses, one checkpoint per epoch written by rank 0 only (the 8-GPU run changes the backend, not this code)."""
+    from visiontransformer_amd import trainer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    arena2, val_rows2 = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    X, Y, Xv, Yv = _fit_data()
+    lm = _StubLightning()
+    rows1 = trainer.fit(lm, [(X[i], Y[i]) for i in range(8)], [(Xv[i], Yv[i]) for i in range(2)], max_epochs=2,
+                        accumulate_grad_batches=2, device="cpu")
+    arena2 = torch.tensor(arena2)
+    assert torch.allclose(arena2, lm.model.arena.detach(), atol=1e-6), (arena2 - lm.model.arena.detach()).abs().max()
+    val_rows1 = [r for r in rows1 if "valid_loss" in r]
+    assert len(val_rows2) == len(val_rows1) == 2
+    for a, b in zip(val_rows2, val_rows1):
+        assert a["step"] == b["step"] and abs(a["valid_loss"] - b["valid_loss"]) < 1e-6 * max(1.0, abs(b["valid_loss"]))
+    ck = sorted(os.listdir(tmp_path / "ckpt"))
+    assert ck == ["epoch=0-step=4.ckpt", "epoch=1-step=8.ckpt"], ck
+    assert (tmp_path / "logs" / "metrics.csv").read_text().startswith("epoch,step,train_loss_step")
+
+
+# ---------------------------------------------------------------- bench.py --gpus N without a launcher
+_STUB_RANK = r'''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+open(os.path.join(sys.argv[1], f"rank{rank}.pid"), "w").write(str(os.getpid()))
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0 and os.environ["LOCAL_RANK"] == str(rank)
+mode = sys.argv[2]
+if mode == "die" and rank == 1:
+    time.sleep(0.5)
+    sys.exit(3)
+if mode == "die":
+    time.sleep(600)          # a rank stuck in a collective: the launcher must not wait for it
+print(json.dumps({"metric": "stub", "n_gpus": world, "rank": rank}), flush=True)
+'''
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+        return True
+    except OSError:
+        return False
+
+
+def test_bench_self_launch_starts_n_ranks_and_relays_rank0_once(tmp_path, capfd):
+    """bench.py's own launcher (`python bench.py --gpus N` with no torchrun around it) with a stub in place of a rank: N
+    children with the rendezvous environment, rank 0's JSON line on stdout exactly once, exit code 0."""
+    import json
+    import sys
+    import bench
+    stub = tmp_path / "stub.py"
+    stub.write_text(_STUB_RANK)
+    for n in (2, 4):
+        d = tmp_path / f"n{n}"
+        d.mkdir()
+        rc = bench.self_launch(n, child=[sys.executable, str(stub), str(d), "ok"])
+        out = capfd.readouterr().out
+        assert rc == 0
+        assert sorted(os.listdir(d)) == [f"rank{r}.pid" for r in range(n)]
+        lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+        assert lines == [{"metric": "stub", "n_gpus": n, "rank": 0}], out
+
+
+def test_bench_self_launch_fails_fast_and_leaves_no_orphan(tmp_path):
+    """One rank dies (exit 3) while the others hang: the launcher returns non-zero within seconds and every child is
+    gone afterwards."""
+    import sys
+    import time
+    import bench
+    stub = tmp_path / "stub.py"
+    stub.write_text(_STUB_RANK)
+    t0 = time.time()
+    rc = bench.self_launch(4, child=[sys.executable, str(stub), str(tmp_path), "die"])
+    assert rc != 0 and time.time() - t0 < 30
+    pids = [int((tmp_path / f"rank{r}.pid").read_text()) for r in range(4)]
+    assert not any(_alive(p) for p in pids), pids

@@ -12,6 +12,10 @@ from visiontransformer_amd.lightning import LightningViTModel
 from visiontransformer_amd.model import ViTSegmentationModel
 
 pytestmark = pytest.mark.gpu
+
+# bf16 gradient gates: 2x the worst per-tensor case the tests below print (relative L2 error / cosine against the fp32 or
+# fp64 gradient of the same step); see the measured values in the test output
+BF16_GRAD_REL, BF16_GRAD_COS = 0.2, 0.98   # (re-pinned after the round-3 GPU run, see below)
 DEV = "cuda:0"
 
 
@@ -247,10 +251,9 @@ def test_paed_trainer_step_gradients_match_oracle():
     sdf_e, sdf_i = torch.rand(2, 64, 64, generator=g) * 4, torch.rand(2, 64, 64, generator=g) * 2
     # oracle: CPU restatement forward + the same loss tail, autograd in fp64
     leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
-    preds = torch.sigmoid(O.forward(x.double(), leaf, cfg))
+    from oracle import paed_oracle as PO   # pinned to the reference's own functions by tests/test_paed_cpu.py
     m = O.resize_target(masks, (96, 96)).unsqueeze(1).double()
-    ref = (torch.nn.functional.binary_cross_entropy(preds, m) + 0.1 * paed.dice_loss(preds, m).double()
-           + 5.0 * paed.paed_loss_soft(sdf_e.unsqueeze(1).double(), sdf_i.unsqueeze(1).double(), preds).abs())
+    ref = PO.binary_total(O.forward(x.double(), leaf, cfg), m, sdf_e.unsqueeze(1).double(), sdf_i.unsqueeze(1).double())
     ref.backward()
     t = paed.PAEDTrainer(1, 16, 192, 2, 3, image_size=96, dropout=0.0, device=DEV).train()
     t.load_state_dict({"model." + k: v for k, v in sd.items()})
@@ -289,7 +292,7 @@ def test_bf16_training_step_close_to_reference(name):
     l32 = lm32.training_step((g.images().to(DEV), g.targets().to(DEV)), 0)
     l32.backward()
     g32 = arena_views(c, lm32.model.arena.grad)
-    worst = 0.0
+    worst, worst_cos = 0.0, 1.0
     for k in gv:
         a, b = gv[k].double().flatten(), g32[k].double().flatten()
         if b.norm() < 1e-6:  # e.g. k_proj.bias: its gradient is identically zero (softmax is shift-invariant)
@@ -297,9 +300,9 @@ def test_bf16_training_step_close_to_reference(name):
             continue
         rel = float((a - b).norm() / b.norm())
         cos = float((a @ b) / (a.norm() * b.norm()))
-        worst = max(worst, rel)
-        assert cos > 0.98 and rel < 0.2, (k, rel, cos)
-    print(f"{name}: bf16 vs fp32 gradients, worst per-tensor relative L2 error {worst:.3e}")
+        worst, worst_cos = max(worst, rel), min(worst_cos, cos)
+        assert cos > BF16_GRAD_COS and rel < BF16_GRAD_REL, (k, rel, cos)
+    print(f"{name}: bf16 vs fp32 gradients, worst per-tensor relative L2 error {worst:.3e}, worst cosine {worst_cos:.5f}")
 
 
 def _dropout_case():
@@ -350,11 +353,15 @@ def test_dropout_bf16_consistent_with_fp32_same_masks():
         m.load_state_dict(sd)
         m.ce_loss(x.to(DEV), y.to(DEV)).backward()  # same seed/step in both -> same masks
         grads[prec] = arena_views(cfg, m.arena.grad.clone())
+    worst, worst_cos = 0.0, 1.0
     for k in grads["fp32"]:
         a, b = grads["bf16"][k].double().flatten(), grads["fp32"][k].double().flatten()
         if b.norm() < 1e-6:
             continue
-        assert float((a - b).norm() / b.norm()) < 0.2 and float((a @ b) / (a.norm() * b.norm())) > 0.98, k
+        rel, cos = float((a - b).norm() / b.norm()), float((a @ b) / (a.norm() * b.norm()))
+        worst, worst_cos = max(worst, rel), min(worst_cos, cos)
+        assert rel < BF16_GRAD_REL and cos > BF16_GRAD_COS, (k, rel, cos)
+    print(f"dropout, bf16 vs fp32 with the same masks: worst relative L2 {worst:.3e}, worst cosine {worst_cos:.5f}")
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 1.2e-1)])   # bf16: the tiny CLS gradient is the noisiest
@@ -391,14 +398,40 @@ def _vitb_512_case(B, L=1, seed=71):
     return cfg, sd, x, y
 
 
-def _grad_check(cfg, arena_grad, leaf, precision):
+def _relu_flip_tokens(stages, cfg, thr=2e-6, limit=16):
+    """Reference-layout token indices (CLS = 0) whose gradient one sign flip of a seg_head.0 ReLU can move: the head
+    applies ReLU to ~10^6 pre-activations; one that lies within fp32 rounding of zero in the fp64 oracle may take the other
+    branch on the GPU, which changes the gradient that flows into the 3x3 token neighbourhood of that unit.  Returns the
+    union of those neighbourhoods (a handful of units at most -- asserted)."""
+    z = stages["head_pre"].detach()
+    near = (z.abs() < thr).nonzero()
+    assert near.shape[0] <= limit, f"{near.shape[0]} head pre-activations within {thr} of zero"
+    g = cfg.grid
+    toks = set()
+    for _, _, y, x in near.tolist():
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if 0 <= y + dy < g and 0 <= x + dx < g:
+                    toks.add(1 + (y + dy) * g + (x + dx))
+    return sorted(toks), int(near.shape[0])
+
+
+def _grad_check(cfg, arena_grad, leaf, precision, stages=None):
     from visiontransformer_amd.params import arena_views
     gv = arena_views(cfg, arena_grad)
-    worst, bad = 0.0, []
+    worst, worst_cos, bad = 0.0, 1.0, []
+    exempt_rows, n_near = _relu_flip_tokens(stages, cfg) if stages is not None else ([], 0)
     for k, r in leaf.items():
         if r.grad is None or "pooler" in k:
             continue
-        a, b = gv[k].cpu().double().flatten(), r.grad.double().flatten()
+        A, Bg = gv[k].cpu().double(), r.grad.double()
+        if precision == "fp32" and exempt_rows and k.endswith("position_embeddings"):
+            # the only tensor indexed by token: leave out exactly the token rows next to a ReLU unit whose fp64
+            # pre-activation is within fp32 rounding of zero (see _relu_flip_tokens); everything else is compared
+            keep = torch.ones(A.shape[1], dtype=torch.bool)
+            keep[exempt_rows] = False
+            A, Bg = A[:, keep], Bg[:, keep]
+        a, b = A.flatten(), Bg.flatten()
         if b.norm() < 1e-7:
             if a.norm() >= 1e-4:
                 bad.append((k, "zero-gradient tensor", float(a.norm())))
@@ -406,20 +439,15 @@ def _grad_check(cfg, arena_grad, leaf, precision):
         rel = float((a - b).norm() / b.norm())
         worst = max(worst, rel)
         if precision == "fp32":
-            # seg_head.0 applies ReLU to ~10^6 pre-activations here: one that lies within fp32 rounding (1e-7) of zero takes
-            # the other branch than in the fp64 oracle, which moves the gradient of its 3x3 neighbourhood of tokens (measured:
-            # 9 token rows of position_embeddings by 3e-7 absolute, 2e-3 of the tensor's norm).  Such a flip is a property of
-            # the comparison, not of the kernels: the gate is the error with the worst 2 % of the elements set aside, plus a
-            # loose bound on everything.
-            err = (a - b).abs()
-            keep = err <= torch.quantile(err[:: max(1, err.numel() // 1_000_000)], 0.98)
-            rel_trim = float(err[keep].norm() / b.norm())
-            if rel_trim >= 2e-4 or rel >= 1e-2 or float(err.max()) > 1e-2 * float(b.abs().max()) + 1e-9:
-                bad.append((k, rel, rel_trim, float(err.max() / b.abs().max())))
-        else:       # bf16 operands (2^-9 relative) through the layer: direction kept, a few per cent of noise
+            if rel >= 2e-4:
+                bad.append((k, rel, float((a - b).abs().max() / b.abs().max())))
+        else:       # bf16 operands (2^-9 relative) through the layer
             cos = float((a @ b) / (a.norm() * b.norm()))
-            if not (cos > 0.98 and rel < 0.2):
+            worst_cos = min(worst_cos, cos)
+            if not (cos > BF16_GRAD_COS and rel < BF16_GRAD_REL):
                 bad.append((k, rel, cos))
+    print(f"gradient check ({precision}): worst relative L2 {worst:.3e}, worst cosine {worst_cos:.5f}, "
+          f"{n_near} head units within fp32 rounding of zero ({len(exempt_rows)} position-embedding rows set aside)")
     assert not bad, bad
     return worst
 
@@ -434,14 +462,15 @@ def test_training_step_vitb_width_512(precision):
     cfg, sd, x, y = _vitb_512_case(B)
     torch.set_num_threads(16)
     leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
-    ref = O.ce_loss(O.forward(x.double(), leaf, cfg), y)
+    stages = {}
+    ref = O.ce_loss(O.forward(x.double(), leaf, cfg, stages=stages), y)
     ref.backward()
     m = ViTSegmentationModel(2, 16, 768, 1, 12, image_size=512, precision=precision, dropout=0.0, device=DEV).train()
     m.load_state_dict(sd)
     loss = m.ce_loss(x.to(DEV), y.to(DEV))
     loss.backward()
     assert abs(float(loss.detach()) - float(ref)) < (2e-6 if precision == "fp32" else 5e-3)
-    worst = _grad_check(cfg, m.arena.grad, leaf, precision)
+    worst = _grad_check(cfg, m.arena.grad, leaf, precision, stages)
     print(f"512x512 ViT-B-width training step, {precision}: worst per-tensor relative L2 gradient error {worst:.3e}")
 
 
@@ -460,10 +489,43 @@ def test_training_step_vitb_width_512_dropout_masks_injected(precision):
     loss.backward()
     masks = Masks(0.1, seed64, B, cfg.num_patches, 12)
     leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
-    ref = O.ce_loss(O.forward(x.double(), leaf, cfg, drop=masks), y)
+    stages = {}
+    ref = O.ce_loss(O.forward(x.double(), leaf, cfg, stages=stages, drop=masks), y)
     ref.backward()
     assert abs(float(loss.detach()) - float(ref)) < (2e-6 if precision == "fp32" else 5e-3)
-    _grad_check(cfg, m.arena.grad, leaf, precision)
+    _grad_check(cfg, m.arena.grad, leaf, precision, stages)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_training_step_vitb16_full_depth_512(p):
+    """BASELINE configs[2] at full depth: ViT-B/16 (D 768, L 12, 12 heads, I 3072) on 512x512 inputs, batch 2, one training
+    step (forward + CE + backward; model/CE/classes.py:276-285 over transformers' modeling_vit.py:164-286) in bf16 mixed
+    precision AND in fp32 against fp64 autograd on the oracle -- every parameter tensor, dense -- with dropout off and with
+    the reference's dropout 0.1 (the build's counter-based masks regenerated in numpy and injected into the oracle)."""
+    from dropout_ref import Masks
+    B = 2
+    cfg, sd, x, y = _vitb_512_case(B, L=12, seed=73)
+    torch.set_num_threads(16)
+    models = {}
+    for prec in ("fp32", "bf16"):
+        m = ViTSegmentationModel(2, 16, 768, 12, 12, image_size=512, precision=prec, dropout=p, device=DEV).train()
+        m.load_state_dict(sd)
+        seed64 = (m.dropout_seed * 0x9E3779B97F4A7C15 + 1 * 0x100000001B3 + 0) & (2 ** 64 - 1)  # first training forward
+        loss = m.ce_loss(x.to(DEV), y.to(DEV))
+        loss.backward()
+        models[prec] = (m, float(loss.detach()), seed64)
+    assert models["fp32"][2] == models["bf16"][2]          # same seed and step: the same masks in both precisions
+    masks = Masks(p, models["fp32"][2], B, cfg.num_patches, 12) if p else None
+    leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    stages = {}
+    ref = O.ce_loss(O.forward(x.double(), leaf, cfg, stages=stages, drop=masks), y)
+    ref.backward()
+    print(f"full-depth ViT-B/16 512x512 step, dropout {p}: loss oracle {float(ref):.6f}, fp32 {models['fp32'][1]:.6f}, "
+          f"bf16 {models['bf16'][1]:.6f}")
+    assert abs(models["fp32"][1] - float(ref)) < 5e-6
+    assert abs(models["bf16"][1] - float(ref)) < 5e-3
+    for prec in ("fp32", "bf16"):
+        _grad_check(cfg, models[prec][0].arena.grad, leaf, prec, stages)
 
 
 @pytest.mark.parametrize("B,Np,A,p", [(2, 256, 2, 0.0), (1, 1024, 2, 0.0), (2, 196, 3, 0.0), (1, 64, 1, 0.0), (2, 100, 2, 0.0),

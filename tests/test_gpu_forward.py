@@ -115,14 +115,15 @@ def test_forward_bf16_close_to_golden(name, precision):
     ref = g.mask()
     mism = (mask.cpu().numpy() != ref).mean()
     print(f"{name}: {precision} logits max-abs err {err:.3e}, mask mismatch rate {mism:.4%}")
-    assert mism < 0.05
+    # measured over the golden cases: bf16 0.01-0.7 %, fp16 0-0.04 % (all at pixels whose top-2 margin is below the logit error)
+    assert mism < (0.015 if precision == "bf16" else 0.001), mism
 
 
 @pytest.mark.parametrize("name", [c for c in CASES if "sat" not in c])
 def test_forward_f32x3_meets_the_fp32_gate(name):
     """precision="fp32x3": fp32 storage, GEMM operands split into half pairs (3 fp16 MFMAs per product), fp32 attention /
     LayerNorm / softmax.  Same gate as the fp32 path: logits within 1e-3 of the reference (measured: a few 1e-6) and
-    masks identical wherever the reference's own decision is not fragile."""
+    masks identical on every pixel the measured logit error cannot flip (O.mask_stable)."""
     g = Golden(name)
     m = build(g, precision="fp32x3")
     x = g.images().to(DEV)
@@ -131,10 +132,17 @@ def test_forward_f32x3_meets_the_fp32_gate(name):
     err, _ = g.max_abs_err("logits", logits)
     print(f"{name}: fp32x3 logits max-abs err {err:.3e}")
     assert err <= 1e-4, err            # 10x tighter than the fp32 gate
+    # masks: identical on every pixel that a logit error of the measured size cannot flip (derived from the reference's
+    # logits, as for the fp32 path -- no hand-kept list)
+    S = g.cfg.image_size
     ref, got = g.mask(), mask.cpu().numpy()
-    bad = (got != ref) & ~g.fragile()
-    print(f"{name}: fp32x3 mask mismatches {int((got != ref).sum())} (outside fragile pixels: {int(bad.sum())})")
+    ref_logits = O.upsample_bilinear(torch.from_numpy(g.z["lowres_logits.full"]), (S, S))
+    stable = O.mask_stable(ref_logits, 2.0 * err + 1e-7).numpy()
+    bad = (got != ref) & stable
+    print(f"{name}: fp32x3 mask mismatches {int((got != ref).sum())} (at stable pixels: {int(bad.sum())}; "
+          f"unstable pixels {(~stable).mean():.3%})")
     assert bad.sum() == 0, int(bad.sum())
+    assert (~stable).mean() < 2e-3 and (got != ref).mean() < 2e-3
 
 
 @pytest.mark.parametrize("name", ["tiny16_224_c2", "base16w_l2_224_c2_train"])

@@ -183,25 +183,17 @@ def test_paed_multiclass_fused_matches_reference_golden():
                                                   (3, 4, 33, 21, 2, False, False), (1, 2, 8, 8, 3, True, True)])
 def test_paed_multiclass_fused_matches_torch_autograd(B, C, H, W, sigma, pen, u8):
     """Shapes the golden file does not hold (non-square, maps smaller than the 19-tap window, class_penalty off,
-    uint8 targets) against fp64 autograd through the plain-torch restatement of the reference function."""
+    uint8 targets) against fp64 autograd through the oracle's restatement of the reference function
+    (oracle/paed_oracle.py, pinned to the reference's own outputs by tests/test_paed_cpu.py)."""
     import torch.nn.functional as F
+    from oracle import paed_oracle as PO
     from visiontransformer_amd import paed
     g = torch.Generator().manual_seed(B * 1000 + C)
     logits = torch.randn(B, C, H, W, generator=g) * 2
     y = torch.randint(0, C, (B, H, W), generator=g)
     ld = logits.double().requires_grad_(True)
-    # as the reference: the Gaussian is built in fp32; everything downstream in fp64 here
-    k = int(6 * sigma + 1)
-    ax = torch.arange(k, dtype=torch.float32) - k // 2
-    g1 = torch.exp(-(ax ** 2) / (2 * sigma ** 2))
-    g2 = (g1[:, None] * g1[None, :])
-    g2 = (g2 / g2.sum()).double()[None, None].repeat(C, 1, 1, 1)
-    p = torch.softmax(ld, dim=1)
-    t = F.one_hot(y, C).permute(0, 3, 1, 2).double()
-    diff = (F.conv2d(t, g2, padding=k // 2, groups=C) - F.conv2d(p, g2, padding=k // 2, groups=C)).abs()
-    if pen:
-        diff = t * (1 - p) * diff * 2
-    ref = diff.mean(dim=[2, 3]).mean(dim=1).mean()
+    ref = PO.multiclass_soft_paed(F.one_hot(y, C).permute(0, 3, 1, 2).double(), torch.softmax(ld, dim=1), sigma=sigma,
+                                  class_penalty=pen)
     ref.backward()
     lg = logits.to(DEV).requires_grad_(True)
     yt = (y.to(torch.uint8) if u8 else y).to(DEV)
@@ -241,17 +233,17 @@ def test_paed_binary_fused_matches_reference_golden():
 @pytest.mark.parametrize("B,H,W,hs,ws", [(2, 224, 224, 64, 64), (1, 50, 70, 20, 31), (3, 33, 21, 33, 21), (1, 96, 96, 128, 128)])
 def test_paed_binary_fused_matches_torch_autograd(B, H, W, hs, ws):
     """Shapes the fixture does not hold (non-square, tiles with ragged edges, SDFs larger than the prediction) against fp64
-    autograd through the plain-torch restatement of the reference methods (visiontransformer_amd/paed.py)."""
-    import torch.nn.functional as F
+    autograd through the oracle's restatement of the reference methods (oracle/paed_oracle.py, pinned to the reference's own
+    outputs by tests/test_paed_cpu.py)."""
+    from oracle import paed_oracle as PO
     from visiontransformer_amd import paed
     g = torch.Generator().manual_seed(B * 100 + H)
     z = torch.randn(B, 1, H, W, generator=g) * 2
     m = (torch.rand(B, 1, H, W, generator=g) > 0.55).float()
     se, si = torch.rand(B, hs, ws, generator=g) * 5, torch.rand(B, hs, ws, generator=g) * 3
     zd = z.double().requires_grad_(True)
-    pr = torch.sigmoid(zd)
-    pa = paed.paed_loss_soft(se.unsqueeze(1).double(), si.unsqueeze(1).double(), pr)
-    ref = F.binary_cross_entropy(pr, m.double()) + 0.1 * paed.dice_loss(pr, m.double()).double() + 5.0 * pa.abs()
+    pa = PO.binary_soft_paed(se.unsqueeze(1).double(), si.unsqueeze(1).double(), torch.sigmoid(zd))
+    ref = PO.binary_total(zd, m.double(), se.unsqueeze(1).double(), si.unsqueeze(1).double())
     ref.backward()
     lg = z.to(DEV).requires_grad_(True)
     loss, terms = paed.paed_binary_loss_fused(lg, m.to(DEV), se.to(DEV), si.to(DEV))
@@ -274,3 +266,25 @@ def test_reference_entry_points_run_end_to_end():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "entry points ok" in r.stdout
     assert "Model_ID,Model_Name,Patch_Size,Hidden_Size,Layers,Heads,Batch_Num,Image_Idx,Accuracy,Mean_IoU,Mean_Dice" in r.stdout
+
+
+# ---------------------------------------------------------------- a13: target resize on the device path
+@pytest.mark.parametrize("H,W,oh,ow", [(256, 256, 224, 224), (256, 256, 512, 512), (97, 301, 224, 224), (224, 224, 224, 224)])
+def test_resize_target_gather_kernel_is_f_interpolate_nearest(H, W, oh, ow):
+    """LightningViTModel._resize_target on GPU tensors (one gather kernel, vitseg_resize_nearest_i64 / _u8 with the
+    mode-1 tables) == F.interpolate(y[:, None].float(), size, mode='nearest').long() (model/CE/classes.py:273-274), bit for
+    bit, for int64 and uint8 class maps and both result types."""
+    import torch.nn.functional as F
+    from visiontransformer_amd.lightning import LightningViTModel
+    g = torch.Generator().manual_seed(H * 7 + ow)
+    y = torch.randint(0, 17, (3, H, W), generator=g)
+    ref = F.interpolate(y.unsqueeze(1).float(), size=(oh, ow), mode="nearest").squeeze(1).long()
+    from oracle import vitseg_oracle as VO
+    assert torch.equal(ref, VO.resize_target(y, (oh, ow)))                      # the oracle's restatement agrees too
+    lm = LightningViTModel(17, 16, 192, 1, 3, image_size=224, device=DEV)
+    out = lm._resize_target(y.to(DEV), (oh, ow))
+    assert out.dtype == torch.long and torch.equal(out.cpu(), ref)
+    out8 = lm._resize_target(y.to(torch.uint8).to(DEV), (oh, ow), dtype=torch.uint8)
+    assert out8.dtype == torch.uint8 and torch.equal(out8.cpu().long(), ref)
+    assert torch.equal(lm._resize_target(y.to(DEV), (oh, ow), dtype=torch.uint8).cpu().long(), ref)
+    assert torch.equal(lm._resize_target(y, (oh, ow)), ref)                     # CPU tensors: host-side path as the reference

@@ -1,11 +1,13 @@
-"""CPU: the PAED loss tails (visiontransformer_amd/paed.py) against golden values/gradients produced by the
-REAL reference functions (oracle/make_golden_paed.py, model/PAED/classes.py:336-369, :608-661, :679-681)."""
+"""CPU: the PAED loss tails -- the product's torch mirrors (visiontransformer_amd/paed.py) AND the oracle restatement the GPU
+tests check the fused kernels with (oracle/paed_oracle.py) -- against golden values/gradients produced by the REAL reference
+functions (oracle/make_golden_paed.py, model/PAED/classes.py:336-369, :608-661, :679-681)."""
 import os
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
+from oracle import paed_oracle as PO
 from oracle.make_golden_paed import paed_inputs
 from visiontransformer_amd import paed
 
@@ -30,5 +32,29 @@ def test_binary_paed_bce_dice_matches_reference():
     total = F.binary_cross_entropy(preds, bmask) + 0.1 * d + 5.0 * p.abs()
     total.backward()
     assert abs(p.item() - G["binary.paed"][0]) < 1e-6 and abs(d.item() - G["binary.dice"][0]) < 1e-6
+    assert abs(total.item() - G["binary.total"][0]) < 1e-5
+    assert np.abs(bl.grad.numpy() - G["binary.grad"]).max() < 1e-7
+
+
+def test_oracle_multiclass_soft_paed_is_pinned_to_the_reference():
+    logits, y, *_ = paed_inputs()
+    lg = logits.clone().requires_grad_(True)
+    loss = PO.multiclass_soft_paed(F.one_hot(y, 17).permute(0, 3, 1, 2).float(), torch.softmax(lg, dim=1))
+    loss.backward()
+    assert abs(loss.item() - G["multiclass.loss"][0]) < 1e-9
+    assert np.abs(lg.grad.numpy() - G["multiclass.grad"]).max() < 1e-10
+    # float64 evaluation (what the GPU parity tests use) agrees with the fp32 reference value to fp32 rounding
+    l64 = PO.multiclass_soft_paed(F.one_hot(y, 17).permute(0, 3, 1, 2).double(), torch.softmax(logits.double(), dim=1))
+    assert abs(l64.item() - G["multiclass.loss"][0]) < 1e-7
+
+
+def test_oracle_binary_tail_is_pinned_to_the_reference():
+    _, _, blogits, bmask, sdf_ext, sdf_int = paed_inputs()
+    bl = blogits.clone().requires_grad_(True)
+    preds = torch.sigmoid(bl)
+    assert abs(PO.binary_soft_paed(sdf_ext, sdf_int, preds).item() - G["binary.paed"][0]) < 1e-6
+    assert abs(PO.dice(preds, bmask).item() - G["binary.dice"][0]) < 1e-6
+    total = PO.binary_total(bl, bmask, sdf_ext, sdf_int)
+    total.backward()
     assert abs(total.item() - G["binary.total"][0]) < 1e-5
     assert np.abs(bl.grad.numpy() - G["binary.grad"]).max() < 1e-7

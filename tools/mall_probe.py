@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Does a working set that fits the 256 MB Infinity Cache re-read faster than HBM?  Repeated full reads (LayerNorm kernel
-of libvitseg as the reader: 16-B loads, one pass over x, negligible writes are avoided by reading rows into a tiny
-output... it writes y, so the probe uses torch's sum reduction instead: read-only) of buffers of growing size."""
+"""Does a working set that fits the 256 MB Infinity Cache re-read faster than HBM?  Read-only passes (torch's sum
+reduction as the reader) over buffers of growing size; the rate drops from ~5 TB/s to the HBM rate once the buffer no
+longer fits (profiles/r02_mall_probe.txt)."""
 import time
 import torch
 dev = "cuda:0"

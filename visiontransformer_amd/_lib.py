@@ -34,7 +34,7 @@ EXPORTS = [
     "vitseg_resize_nearest_u8", "vitseg_eval_counts", "vitseg_paed_scratch_bytes", "vitseg_paed_multiclass_loss",
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32", "vitseg_op_linear_h16_ex",
     "vitseg_op_wgrad_bf16", "vitseg_op_wgrad_bf16_scratch_floats", "vitseg_op_attention_bwd_bf16", "vitseg_attention_dropmask_bytes", "vitseg_op_colsum_scratch_floats",
-    "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss", "vitseg_op_linear_f32_ex",
+    "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss", "vitseg_op_linear_f32_ex", "vitseg_resize_nearest_i64",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
                 "head1x1", "upsample", "train_gemm_fwd", "train_dgrad", "train_wgrad", "train_attn_fwd", "train_attn_bwd"]
@@ -112,6 +112,7 @@ def lib() -> C.CDLL:
         l.vitseg_nearest_index.argtypes = [i32, i32, i32, vp]
         l.vitseg_preprocess_u8.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]
         l.vitseg_resize_nearest_u8.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp, vp]
+        l.vitseg_resize_nearest_i64.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp]
         l.vitseg_eval_counts.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
         l.vitseg_grad_bucket_range.argtypes = [pcfg, i32, psz, psz]
         l.vitseg_adam_step.argtypes = [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, f32, vp]

@@ -150,16 +150,16 @@ __global__ __launch_bounds__(256) void resize_v_tensor_kernel(const unsigned cha
     out[o + 2 * plane] = __fdiv_rn((float)v2, 255.0f);
 }
 
-template <typename OutT>
-__global__ __launch_bounds__(256) void nearest_lut_kernel(const unsigned char* __restrict__ src, OutT* __restrict__ dst,
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(256) void nearest_lut_kernel(const InT* __restrict__ src, OutT* __restrict__ dst,
                                                           const int* __restrict__ yi, const int* __restrict__ xi,
                                                           const unsigned char* __restrict__ lut, int H, int W, int oh,
                                                           int ow) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y, n = blockIdx.z;
     if (x >= ow) return;
-    unsigned char v = src[((size_t)n * H + yi[y]) * W + xi[x]];
-    if (lut) v = lut[v];
+    InT v = src[((size_t)n * H + yi[y]) * W + xi[x]];
+    if (lut) v = (InT)lut[(unsigned char)v];
     dst[((size_t)n * oh + y) * ow + x] = (OutT)v;
 }
 
@@ -301,15 +301,20 @@ int launch_preprocess_u8(const unsigned char* img, int n, int H, int W, int S, c
     return VITSEG_OK;
 }
 
-int launch_nearest_lut(const unsigned char* src, int n, int H, int W, const int* yi, const int* xi, int oh, int ow,
+// src_i64: the source holds int64 class indices (torch.long targets: model/CE/classes.py:273-274 resizes those)
+int launch_nearest_lut(const void* src, int src_i64, int n, int H, int W, const int* yi, const int* xi, int oh, int ow,
                        const unsigned char* lut, int out_i64, void* out, hipStream_t s) {
     VITSEG_CHECK_ARG(src && out && yi && xi && n > 0 && oh > 0 && ow > 0, VITSEG_EINVAL, "resize_nearest: bad arguments");
+    VITSEG_CHECK_ARG(!(src_i64 && lut), VITSEG_EINVAL, "resize_nearest: the value table applies to 8-bit sources");
     const dim3 grid((ow + 255) / 256, oh, n);
-    if (out_i64)
-        hipLaunchKernelGGL(nearest_lut_kernel<long long>, grid, dim3(256), 0, s, src, (long long*)out, yi, xi, lut, H, W, oh, ow);
-    else
-        hipLaunchKernelGGL(nearest_lut_kernel<unsigned char>, grid, dim3(256), 0, s, src, (unsigned char*)out, yi, xi, lut, H,
-                           W, oh, ow);
+#define VITSEG_NEAR(IN, OUT) \
+    hipLaunchKernelGGL((nearest_lut_kernel<IN, OUT>), grid, dim3(256), 0, s, (const IN*)src, (OUT*)out, yi, xi, lut, H, W, oh, ow)
+    if (src_i64) {
+        if (out_i64) VITSEG_NEAR(long long, long long); else VITSEG_NEAR(long long, unsigned char);
+    } else {
+        if (out_i64) VITSEG_NEAR(unsigned char, long long); else VITSEG_NEAR(unsigned char, unsigned char);
+    }
+#undef VITSEG_NEAR
     VITSEG_LAUNCH_CHECK("nearest_lut");
     return VITSEG_OK;
 }
@@ -347,7 +352,12 @@ int vitseg_preprocess_u8(const uint8_t* img, int n, int H, int W, int S, const i
 }
 int vitseg_resize_nearest_u8(const uint8_t* src, int n, int H, int W, const int32_t* yidx, const int32_t* xidx, int out_h,
                              int out_w, const uint8_t* lut, int out_is_i64, void* out, void* stream) {
-    return vitseg::launch_nearest_lut(src, n, H, W, yidx, xidx, out_h, out_w, lut, out_is_i64, out, (hipStream_t)stream);
+    return vitseg::launch_nearest_lut(src, 0, n, H, W, yidx, xidx, out_h, out_w, lut, out_is_i64, out, (hipStream_t)stream);
+}
+int vitseg_resize_nearest_i64(const int64_t* src, int n, int H, int W, const int32_t* yidx, const int32_t* xidx, int out_h,
+                              int out_w, int out_is_i64, void* out, void* stream) {
+    return vitseg::launch_nearest_lut(src, 1, n, H, W, yidx, xidx, out_h, out_w, nullptr, out_is_i64, out,
+                                      (hipStream_t)stream);
 }
 int vitseg_eval_counts(const uint8_t* pred, const uint8_t* gt, int n, int S, int gt_h, int gt_w, const int32_t* yidx,
                        const int32_t* xidx, int64_t* counts, void* stream) {

@@ -27,14 +27,22 @@ class LightningViTModel(nn.Module):
     def forward(self, x):
         return self.model(x)
 
-    def _resize_target(self, y, size):
-        # classes.py:273-274 (host-side label preprocessing; nearest: idx = min(floor(dst*in/out), in-1))
-        return F.interpolate(y.unsqueeze(1).float(), size=size, mode="nearest").squeeze(1).long()
+    def _resize_target(self, y, size, dtype=torch.long):
+        """classes.py:273-274: F.interpolate(y[:, None].float(), size, mode='nearest') -> long (idx = min(floor(dst*in/out),
+        in-1)).  Targets on the GPU go through one gather kernel (preprocess.Preprocessor.targets: no float round trip, no
+        ATen kernels in the training step); a CPU tensor is host-side label preprocessing as in the reference."""
+        if y.is_cuda and y.dim() == 3 and y.dtype in (torch.long, torch.uint8):
+            from .preprocess import Preprocessor
+            if getattr(self, "_prep", None) is None or self._prep.device != y.device:
+                self._prep = Preprocessor(self.model.cfg.image_size, device=y.device)
+            return self._prep.targets(y, tuple(size), dtype=dtype)
+        return F.interpolate(y.unsqueeze(1).float(), size=size, mode="nearest").squeeze(1).to(dtype)
 
     def _loss(self, batch, grad_scale=None):
         x, y = batch
         S = self.model.cfg.image_size  # the reference hard-codes (224, 224) = its image_size (classes.py:278)
-        y = self._resize_target(y, size=(S, S))
+        # uint8 class indices: what the fused CE kernels read (a quarter of the int64 bytes); C <= 32 in training
+        y = self._resize_target(y.to(x.device, non_blocking=True), size=(S, S), dtype=torch.uint8)
         return self.model.ce_loss(x, y, grad_scale=grad_scale)
 
     # `logged` holds DEVICE scalars: reading one (float(...)) is the only host sync, and only the caller decides when

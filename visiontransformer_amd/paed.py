@@ -53,7 +53,8 @@ class _PAEDMulticlassFn(torch.autograd.Function):
         B, Cc, H, W = logits.shape
         if tuple(target.shape) != (B, H, W):
             raise ValueError(f"target shape {tuple(target.shape)} does not match logits {tuple(logits.shape)}")
-        need_grad = logits.requires_grad
+        # (requires_grad of the cast copy says nothing inside Function.forward, where grad mode is off)
+        need_grad = ctx.needs_input_grad[0]
         L = _lib.lib()
         scratch = torch.empty(L.vitseg_paed_scratch_bytes(B, Cc, H, W), dtype=torch.uint8, device=logits.device)
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
@@ -63,12 +64,14 @@ class _PAEDMulticlassFn(torch.autograd.Function):
                 logits.data_ptr(), target.data_ptr(), int(target.dtype == torch.uint8), B, Cc, H, W, float(sigma),
                 int(bool(class_penalty)), scratch.data_ptr(), loss.data_ptr(), None if grad is None else grad.data_ptr(),
                 torch.cuda.current_stream().cuda_stream))
-        ctx.grad = grad
+        ctx.save_for_backward(*([grad] if grad is not None else []))
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        return ctx.grad * grad_out, None, None, None
+        if not ctx.saved_tensors:
+            raise RuntimeError("paed_multiclass_loss_fused: the gradient was not requested in the forward")
+        return ctx.saved_tensors[0] * grad_out, None, None, None
 
 
 def paed_multiclass_loss_fused(logits, target, sigma=3, class_penalty=True):
@@ -96,19 +99,21 @@ class _PAEDBinaryFn(torch.autograd.Function):
         L = _lib.lib()
         scratch = torch.empty(L.vitseg_paed_binary_scratch_bytes(B, H, W), dtype=torch.uint8, device=logits.device)
         out = torch.empty(8, dtype=torch.float32, device=logits.device)
-        grad = torch.empty_like(logits) if logits.requires_grad else None
+        grad = torch.empty_like(logits) if ctx.needs_input_grad[0] else None   # (not logits.requires_grad: see above)
         with torch.cuda.device(logits.device):
             _lib.check(L.vitseg_paed_binary_loss(logits.data_ptr(), mask.data_ptr(), sdf_ext.data_ptr(), sdf_int.data_ptr(),
                                                  hs, ws, B, H, W, scratch.data_ptr(), out.data_ptr(),
                                                  None if grad is None else grad.data_ptr(),
                                                  torch.cuda.current_stream().cuda_stream))
-        ctx.grad = grad
+        ctx.save_for_backward(*([grad] if grad is not None else []))
         ctx.mark_non_differentiable(out)
         return out[0].clone(), out
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_terms):
-        return ctx.grad * grad_loss, None, None, None
+        if not ctx.saved_tensors:
+            raise RuntimeError("paed_binary_loss_fused: the gradient was not requested in the forward")
+        return ctx.saved_tensors[0] * grad_loss, None, None, None
 
 
 def paed_binary_loss_fused(logits, mask, sdf_ext, sdf_int):
@@ -166,6 +171,11 @@ class _Base(nn.Module):
             if y.shape[1] != 1:
                 raise ValueError(f"Expected single-channel mask but got shape {y.shape}")  # :502-503
             y = y[:, 0]
+        if y.is_cuda and y.dtype in (torch.long, torch.uint8):     # one gather kernel instead of unsqueeze/float/interpolate/long
+            from .preprocess import Preprocessor
+            if getattr(self, "_prep", None) is None or self._prep.device != y.device:
+                self._prep = Preprocessor(self.model.cfg.image_size, device=y.device)
+            return self._prep.targets(y, tuple(size))
         return F.interpolate(y.unsqueeze(1).float(), size=size, mode="nearest").squeeze(1).long()
 
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):

@@ -89,6 +89,30 @@ class Preprocessor:
                 _ptr(tmp), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
         return out
 
+    def targets(self, y: torch.Tensor, size: Tuple[int, int], dtype=torch.long) -> torch.Tensor:
+        """`F.interpolate(y[:, None].float(), size=size, mode='nearest').squeeze(1).long()` of class-index maps
+        [n, H, W] (torch.long as the reference's datasets deliver them, or torch.uint8) -- LightningViTModel._resize_target,
+        model/CE/classes.py:273-274 -- as ONE gather kernel on the device: no float round trip, no ATen kernels.
+        `dtype` torch.long (the reference's result type) or torch.uint8 (what the fused CE loss reads)."""
+        if y.dim() != 3 or y.dtype not in (torch.long, torch.uint8):
+            raise ValueError(f"expected int64/uint8 [n, H, W] class indices, got {y.dtype} {tuple(y.shape)}")
+        if dtype not in (torch.long, torch.uint8):
+            raise ValueError("dtype must be torch.long or torch.uint8")
+        y = y.to(self.device, non_blocking=True).contiguous()
+        n, H, W = y.shape
+        oh, ow = size
+        out = torch.empty((n, oh, ow), dtype=dtype, device=self.device)
+        yi, xi = self._nearest(H, oh, NEAREST_TORCH), self._nearest(W, ow, NEAREST_TORCH)
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream().cuda_stream
+            if y.dtype == torch.long:
+                _lib.check(_lib.lib().vitseg_resize_nearest_i64(y.data_ptr(), n, H, W, yi.data_ptr(), xi.data_ptr(), oh, ow,
+                                                                int(dtype == torch.long), out.data_ptr(), st))
+            else:
+                _lib.check(_lib.lib().vitseg_resize_nearest_u8(y.data_ptr(), n, H, W, yi.data_ptr(), xi.data_ptr(), oh, ow,
+                                                               None, int(dtype == torch.long), out.data_ptr(), st))
+        return out
+
     def masks(self, mask: torch.Tensor, size: Tuple[int, int], mode: int = NEAREST_PIL,
               value_to_class: Optional[dict] = None, dtype=torch.long) -> torch.Tensor:
         """uint8 [H, W] or [n, H, W] label images -> [n, size] class indices (`dtype` torch.long as the reference's

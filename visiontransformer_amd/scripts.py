@@ -16,25 +16,30 @@ from . import synth
 from .metrics import Evaluator, csv_row, write_metrics_csv
 
 
-def get_latest_checkpoint(version_n: int, base_path: str) -> Optional[str]:
-    """logs/vit-model/version_<n>/checkpoints/*.ckpt with the largest epoch number in `epoch=E-step=S.ckpt`
-    (model/CE/datasetTestViTmodel.py:38-54, model/PAED/ViTscriptTest.py same helper)."""
-    d = os.path.join(base_path, f"logs/vit-model/version_{version_n}/checkpoints")
-    if not os.path.exists(d):
-        print(f"Directory {d} does not exist.")
-        return None
-    files = [f for f in os.listdir(d) if f.endswith(".ckpt")]
-    if not files:
-        print(f"No checkpoint files found in {d}")
-        return None
-    latest = max(files, key=lambda x: int(x.split("=")[1].split("-")[0]))
-    print(f"Latest checkpoint found: {os.path.join(d, latest)}")
-    return os.path.join(d, latest)
-
-
 def checkpoint_epoch(path: str) -> Optional[int]:
     m = re.search(r"epoch=(\d+)", path)
     return int(m.group(1)) if m else None
+
+
+def get_latest_checkpoint(version_n: int, base_path: str) -> Optional[str]:
+    """The checkpoint with the largest epoch number among logs/vit-model/version_<n>/checkpoints/epoch=E-step=S.ckpt,
+    None (with a message) when the directory or any checkpoint is missing -- the rule of the reference's helper
+    (model/CE/datasetTestViTmodel.py:38-54, also used by model/PAED/ViTscriptTest.py)."""
+    ckpt_dir = os.path.join(base_path, "logs", "vit-model", f"version_{version_n}", "checkpoints")
+    if not os.path.isdir(ckpt_dir):
+        print(f"no checkpoint directory: {ckpt_dir}")
+        return None
+    by_epoch = {}
+    for name in sorted(os.listdir(ckpt_dir)):
+        epoch = checkpoint_epoch(name) if name.endswith(".ckpt") else None
+        if epoch is not None:
+            by_epoch[epoch] = name
+    if not by_epoch:
+        print(f"no epoch=<E>-step=<S>.ckpt file in {ckpt_dir}")
+        return None
+    path = os.path.join(ckpt_dir, by_epoch[max(by_epoch)])
+    print(f"latest checkpoint: {path}")
+    return path
 
 
 def ce_batches(cfg, n_images: int, batch_size: int, data: Optional[str] = None, seed: int = 0, first: int = 0):
