@@ -13,9 +13,13 @@ from visiontransformer_amd.model import ViTSegmentationModel
 
 pytestmark = pytest.mark.gpu
 
-# bf16 gradient gates: 2x the worst per-tensor case the tests below print (relative L2 error / cosine against the fp32 or
-# fp64 gradient of the same step); see the measured values in the test output
-BF16_GRAD_REL, BF16_GRAD_COS = 0.2, 0.98   # (re-pinned after the round-3 GPU run, see below)
+# bf16 gradient gates (per-tensor relative L2 error / cosine against the fp32 or fp64 gradient of the same step) = 2x the
+# worst case measured on MI355X in round 3 (the tests print it; gpurun_out/r03_gpu_all_*.log).  The noise grows with
+# depth: bf16 operands (2^-9) through 1-2 layers give <= 5.1e-2 / 0.9987, through 12 layers 0.14 / 0.991 (Tiny width) and
+# 0.22 / 0.976 (ViT-B/16 at 512x512, worst tensor; the gradient as a whole: see the full-depth test).
+BF16_GRAD_REL, BF16_GRAD_COS = 0.10, 0.997            # <= 2 layers
+BF16_GRAD_REL_L12, BF16_GRAD_COS_L12 = 0.27, 0.982    # 12 layers, Tiny width
+BF16_GRAD_REL_B16, BF16_GRAD_COS_B16 = 0.45, 0.95     # 12 layers, ViT-B/16 at 512x512
 DEV = "cuda:0"
 
 
@@ -301,7 +305,9 @@ def test_bf16_training_step_close_to_reference(name):
         rel = float((a - b).norm() / b.norm())
         cos = float((a @ b) / (a.norm() * b.norm()))
         worst, worst_cos = max(worst, rel), min(worst_cos, cos)
-        assert cos > BF16_GRAD_COS and rel < BF16_GRAD_REL, (k, rel, cos)
+        deep = c.num_hidden_layers > 2
+        assert cos > (BF16_GRAD_COS_L12 if deep else BF16_GRAD_COS) and rel < (BF16_GRAD_REL_L12 if deep else BF16_GRAD_REL), \
+            (k, rel, cos)
     print(f"{name}: bf16 vs fp32 gradients, worst per-tensor relative L2 error {worst:.3e}, worst cosine {worst_cos:.5f}")
 
 
@@ -416,10 +422,12 @@ def _relu_flip_tokens(stages, cfg, thr=2e-6, limit=16):
     return sorted(toks), int(near.shape[0])
 
 
-def _grad_check(cfg, arena_grad, leaf, precision, stages=None):
+def _grad_check(cfg, arena_grad, leaf, precision, stages=None, bf16_gates=None):
     from visiontransformer_amd.params import arena_views
     gv = arena_views(cfg, arena_grad)
-    worst, worst_cos, bad = 0.0, 1.0, []
+    rel_gate, cos_gate = bf16_gates or (BF16_GRAD_REL, BF16_GRAD_COS)
+    worst, worst_cos, bad, worst_name = 0.0, 1.0, [], ""
+    num, den = 0.0, 0.0
     exempt_rows, n_near = _relu_flip_tokens(stages, cfg) if stages is not None else ([], 0)
     for k, r in leaf.items():
         if r.grad is None or "pooler" in k:
@@ -437,19 +445,23 @@ def _grad_check(cfg, arena_grad, leaf, precision, stages=None):
                 bad.append((k, "zero-gradient tensor", float(a.norm())))
             continue
         rel = float((a - b).norm() / b.norm())
-        worst = max(worst, rel)
+        num, den = num + float((a - b).pow(2).sum()), den + float(b.pow(2).sum())
+        if rel > worst:
+            worst, worst_name = rel, k
         if precision == "fp32":
             if rel >= 2e-4:
                 bad.append((k, rel, float((a - b).abs().max() / b.abs().max())))
         else:       # bf16 operands (2^-9 relative) through the layer
             cos = float((a @ b) / (a.norm() * b.norm()))
             worst_cos = min(worst_cos, cos)
-            if not (cos > BF16_GRAD_COS and rel < BF16_GRAD_REL):
+            if not (cos > cos_gate and rel < rel_gate):
                 bad.append((k, rel, cos))
-    print(f"gradient check ({precision}): worst relative L2 {worst:.3e}, worst cosine {worst_cos:.5f}, "
+    whole = (num / max(den, 1e-300)) ** 0.5
+    print(f"gradient check ({precision}): worst relative L2 {worst:.3e} ({worst_name}), worst cosine {worst_cos:.5f}, "
+          f"whole gradient {whole:.3e}, "
           f"{n_near} head units within fp32 rounding of zero ({len(exempt_rows)} position-embedding rows set aside)")
     assert not bad, bad
-    return worst
+    return worst, whole
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -470,7 +482,7 @@ def test_training_step_vitb_width_512(precision):
     loss = m.ce_loss(x.to(DEV), y.to(DEV))
     loss.backward()
     assert abs(float(loss.detach()) - float(ref)) < (2e-6 if precision == "fp32" else 5e-3)
-    worst = _grad_check(cfg, m.arena.grad, leaf, precision, stages)
+    worst, _ = _grad_check(cfg, m.arena.grad, leaf, precision, stages)
     print(f"512x512 ViT-B-width training step, {precision}: worst per-tensor relative L2 gradient error {worst:.3e}")
 
 
@@ -525,7 +537,9 @@ def test_training_step_vitb16_full_depth_512(p):
     assert abs(models["fp32"][1] - float(ref)) < 5e-6
     assert abs(models["bf16"][1] - float(ref)) < 5e-3
     for prec in ("fp32", "bf16"):
-        _grad_check(cfg, models[prec][0].arena.grad, leaf, prec, stages)
+        _, whole = _grad_check(cfg, models[prec][0].arena.grad, leaf, prec, stages, (BF16_GRAD_REL_B16, BF16_GRAD_COS_B16))
+        # the gradient as ONE vector (what the optimizer sees): fp32 1e-5, bf16 a few per cent
+        assert whole < (1e-4 if prec == "fp32" else 0.15), (prec, whole)
 
 
 @pytest.mark.parametrize("B,Np,A,p", [(2, 256, 2, 0.0), (1, 1024, 2, 0.0), (2, 196, 3, 0.0), (1, 64, 1, 0.0), (2, 100, 2, 0.0),

@@ -14,6 +14,8 @@
 //       ds_read_b64_tr_b16 per k-step (hardware transpose; lane 4q+p of a 16-lane group supplies
 //       &V[key0+q][d0+4p] and receives V[key0..key0+3][d0 + lane] -- verified by tools/probes/tr16_probe.hip).
 // Scores are scaled inside the exponent: p = exp2(fma(s, c, -m*c)), c = hd^-0.5 * log2(e).
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace vitseg {
@@ -107,25 +109,41 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
         }
     }
 
-    // ---- K/V staging: thread owns 16-B chunk lc (8 bf16) of keys lr + 32 i ----
-    const int lc = tid & 7, lr = tid >> 3;
-    f32x4 rk[2], rv[2];
-    auto gload = [&](int kt) {
+    // ---- K/V staging by LDS-DMA: a wave instruction moves 8 keys x 128 B straight into the tile (lane l lands at
+    // + 16 l: key l >> 3, chunk position l & 7; the XOR swizzles of the two images are applied to the per-lane SOURCE
+    // chunk).  ONE buffer descriptor over this image's K|V rows; the per-lane offset is a loop constant and the tile's
+    // row offset a scalar, so staging costs no vector instruction, no staging registers and no ds_write (the flat-load
+    // form spent ~45 VALU per tile on addresses and 16 VGPRs on the hop; the loop is VALU-bound:
+    // profiles/r03_pmcw_attn_fwd_serial.json, 0.73 VALU active).  Rows beyond the image's last patch are out of the
+    // descriptor's range and read as zeros (RAGGED masks their scores).  Issued from inline asm and ordered by one
+    // hand-placed vmcnt(0) before the tile's barrier (the loop has no other vector-memory instruction).
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 kv_rsrc;
+    {
+        const unsigned long long base = (unsigned long long)(kbase + row0 * ld);
+        kv_rsrc[0] = (int)(unsigned)base;
+        kv_rsrc[1] = (int)(unsigned)((base >> 32) & 0xffffu);   // stride 0
+        kv_rsrc[2] = Np * ld * 2;                                // bytes from the first patch row to the end of the image
+        kv_rsrc[3] = 0x00020000;
+    }
+    const int drow = 16 * __builtin_amdgcn_readfirstlane(wave) + (lane >> 3);   // key of this lane in piece 0; piece 1: + 8
+    unsigned voff_k[2], voff_v[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int key = kt * KB + lr + 32 * i;
-            if (RAGGED) key = min(key, Np - 1);  // duplicates are masked below
-            const size_t off = (row0 + key) * ld + 8 * lc;
-            rk[i] = *(const f32x4*)(kbase + off);
-            rv[i] = *(const f32x4*)(vbase + off);
-        }
-    };
-    auto swrite = [&](int buf) {
+    for (int pc = 0; pc < 2; ++pc) {
+        const int key = drow + 8 * pc;
+        voff_k[pc] = (unsigned)(key * ld * 2 + (((lane & 7) ^ ((key >> 1) & 7)) << 4));
+        voff_v[pc] = (unsigned)(key * ld * 2 + D * 2 + (((lane & 7) ^ (((key >> 1) & 1) << 2)) << 4));
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&lds[0][0][0];
+    auto stage = [&](int kt, int buf) {   // tile kt -> ring slot buf
+        const unsigned soff = (unsigned)(kt * KB * ld * 2);
+        const unsigned dst = lds_base + (unsigned)(buf * 2 * KB * HD * 2) + (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 2048);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = lr + 32 * i;
-            *(f32x4*)&lds[buf][0][key * HD + ((lc ^ ((key >> 1) & 7)) << 3)] = rk[i];        // K: row reads
-            *(f32x4*)&lds[buf][1][key * HD + ((lc ^ (((key >> 1) & 1) << 2)) << 3)] = rv[i];  // V: transposed reads
+        for (int pc = 0; pc < 2; ++pc) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst + pc * 1024), "v"(voff_k[pc]), "s"(kv_rsrc), "s"(soff) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst + KB * HD * 2 + pc * 1024), "v"(voff_v[pc]), "s"(kv_rsrc), "s"(soff) : "memory");
         }
     };
     // per-lane LDS element offsets
@@ -146,42 +164,80 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
     }
     TileMasks lm;
     if (MW) lm.load(mrow);
-    gload(0);
-    swrite(0);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // One 64-key tile.
+    // No running-maximum pass: the tile is exponentiated against the CURRENT m (p = exp2(c s - c m)) and only its
+    // per-lane sum is looked at -- when some lane's sum exceeds 2^16 (or is not finite) m was too low for this tile, and
+    // the rare path below raises it to the tile's maximum, rescales O and l and exponentiates again.  Otherwise every
+    // p <= 2^16: exact in the fp32 sums, harmless in the 16-bit P (same exponent range as fp32 for bf16; IEEE half
+    // holds 65 504, so the fp16 build uses 2^12).  That removes 16 v_max3, an LDS round trip and a compare per tile.
+    constexpr float PSUM_LIMIT = sizeof(H) == 2 && std::is_same<H, f16_t>::value ? 4096.f : 65536.f;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (MW) lm.wait();
-        gload(min(kt + 1, nkt - 1));  // the last tile re-stages itself: keeps the body branch-free
+        stage(min(kt + 1, nkt - 1), buf ^ 1);  // the last tile re-stages itself: keeps the body branch-free
         const bf16_t* Ks = lds[buf][0];
         const bf16_t* Vs = lds[buf][1];
 
-        // S^T[key][query] - m, two blocks of 32 keys
+        // S^T[key][query], two blocks of 32 keys
         f32x16 st[2];
+        auto scores = [&]() {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;   // inline-constant C operand of the first MFMA: no moves
+                for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;   // inline-constant C operand of the first MFMA: no moves
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f32x4 kf = *(const f32x4*)&Ks[kb * 32 * HD + k_off + (((2 * s + lh) ^ k_sw) << 3)];
-                st[kb] = H16<H>::mfma(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), st[kb]);
+                for (int s = 0; s < 4; ++s) {
+                    const f32x4 kf = *(const f32x4*)&Ks[kb * 32 * HD + k_off + (((2 * s + lh) ^ k_sw) << 3)];
+                    st[kb] = H16<H>::mfma(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), st[kb]);
+                }
             }
-        }
-        if (RAGGED) {
+            if (RAGGED) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt * KB + kb * 32 + kappa(r, lh) >= Np) st[kb][r] = -INFINITY;
+            }
+        };
+        scores();
+        float nmc = -m_run * c;   // p = exp2(c s - c m): the running maximum enters through the fma's addend
+        float psum;
+        unsigned pk[2][8];  // P^T fragments: pk[kb][4 s + w] = registers 8 s + 2 w, 8 s + 2 w + 1
+        auto exponentiate = [&]() {
+            float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kt * KB + kb * 32 + kappa(r, lh) >= Np) st[kb][r] = -INFINITY;
-        }
-        float mx = fmaxf(st[0][0], st[1][0]);
+                for (int r = 0; r < 16; r += 2) {
+                    float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, nmc));
+                    float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c, nmc));
+                    ps0 += p0;
+                    ps1 += p1;
+                    if (MW) {
+                        p0 = mask_select(lm.reg(kb, r), p0);
+                        p1 = mask_select(lm.reg(kb, r + 1), p1);
+                    } else if (DROP) {
+                        const unsigned k0 = (unsigned)(kt * KB + kb * 32);
+                        p0 = drop_keep(dkey, k0 + kappa(r, lh), dr.thresh) ? p0 * dr.scale : 0.f;
+                        p1 = drop_keep(dkey, k0 + kappa(r + 1, lh), dr.thresh) ? p1 * dr.scale : 0.f;
+                    }
+                    pk[kb][r >> 1] = H16<H>::pack2(p0, p1);
+                    // pin the pack HERE: otherwise hipcc sinks all 16 of them below the guard branch and keeps the 32
+                    // fp32 probabilities alive across it (+16 registers = one wave per SIMD less)
+                    asm volatile("" : "+v"(pk[kb][r >> 1]));
+                }
+            psum = ps0 + ps1;
+        };
+        exponentiate();
+        if (__builtin_amdgcn_ballot_w64(!(psum <= PSUM_LIMIT)) != 0) {   // wave-uniform, rare after the first tiles
+            scores();            // again, rather than keeping 32 score registers alive across the common path
+            float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
-        for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, st[0][r]), st[1][r]);  // v_max3_f32
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // the running maximum settles after the first few key tiles: m, O and l move only when some lane's scores
-        // exceed it by more than the threshold (wave-uniform branch)
-        if (__builtin_amdgcn_ballot_w64(mx - m_run > DEFER_THR * (1.0f / (0.125f * LOG2E))) != 0) {
+            for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, st[0][r]), st[1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float delta = fmaxf(mx - m_run, 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-delta * c);
             l_run *= alpha;
@@ -190,27 +246,9 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             m_run += delta;
+            nmc = -m_run * c;
+            exponentiate();      // now every p <= 1
         }
-        const float nmc = -m_run * c;   // p = exp2(c s - c m): the running maximum enters through the fma's addend
-        float psum = 0.f;
-        unsigned pk[2][8];  // P^T fragments: pk[kb][4 s + w] = registers 8 s + 2 w, 8 s + 2 w + 1
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, nmc));
-                float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c, nmc));
-                psum += p0 + p1;
-                if (MW) {
-                    p0 = mask_select(lm.reg(kb, r), p0);
-                    p1 = mask_select(lm.reg(kb, r + 1), p1);
-                } else if (DROP) {
-                    const unsigned k0 = (unsigned)(kt * KB + kb * 32);
-                    p0 = drop_keep(dkey, k0 + kappa(r, lh), dr.thresh) ? p0 * dr.scale : 0.f;
-                    p1 = drop_keep(dkey, k0 + kappa(r + 1, lh), dr.thresh) ? p1 * dr.scale : 0.f;
-                }
-                pk[kb][r >> 1] = H16<H>::pack2(p0, p1);
-            }
         l_run += psum;
 
         // O^T[d][query] += V^T[d][key] . P^T[key][query]
@@ -234,7 +272,7 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
             }
 
         if (MW) lm.load(mrow + (size_t)min(kt + 1, nkt - 1) * 32);   // next tile's lane masks (see TileMasks)
-        swrite(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 have landed
         __syncthreads();
     }
 
