@@ -89,6 +89,33 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int t0, int dt, in
     return f;
 }
 
+// LDS-DMA staging of one [64 tokens][64 d] tile (the layout of tile_off): a wave instruction moves 8 token rows x 128 B
+// straight into the tile (lane l lands at + 16 l: row l >> 3, chunk position l & 7; tile_off's XOR is applied to the per-lane
+// SOURCE chunk).  One buffer descriptor per tensor, per-lane offsets are loop constants, the tile's row offset a scalar: no
+// vector instruction, no staging registers, no ds_write per tile (the flat-load form spent ~30 VALU per tile on 64-bit
+// addresses and 16 VGPRs on the hop, at two waves per SIMD).  Rows beyond the descriptor's range read as zeros.  Issued from
+// inline asm; the caller orders it with one hand-placed vmcnt(0) before the tile's barrier.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, int bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 r;
+    r[0] = (int)(unsigned)b;
+    r[1] = (int)(unsigned)((b >> 32) & 0xffffu);   // stride 0
+    r[2] = bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+// byte offset of this lane's 16 bytes inside the source tile whose rows are `row_bytes` apart: piece pc of wave `wave`
+__device__ __forceinline__ unsigned dma_voff(int wave, int pc, int lane, int row_bytes) {
+    const int row = 16 * wave + 8 * pc + (lane >> 3);
+    const int x = (row >> 1) & 7;
+    return (unsigned)(row * row_bytes + ((((lane & 7)) ^ (((x & 1) << 2) | (x >> 1))) << 4));
+}
+__device__ __forceinline__ void dma_piece(unsigned lds_dst, unsigned voff, const i32x4& rsrc, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 // partial dot product of two 8 x 4 bf16-pair fragments (this lane's 32 of the 64 channels), completed across the lane halves
 __device__ __forceinline__ float dot_frag(const f32x4 (&a)[4], const f32x4 (&b)[4]) {
     float part = 0.f;
@@ -107,7 +134,7 @@ __device__ __forceinline__ float dot_frag(const f32x4 (&a)[4], const f32x4 (&b)[
 // MW (both MFMA kernels; with DROP, without RAGGED): keep bits from the precomputed words (common.hpp
 // attn_dropmask_words) instead of one hash per element.
 template <bool DROP, bool RAGGED, bool MW>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                   const bf16_t* __restrict__ dctx,
                                                                   const float* __restrict__ lse,
                                                                   const float* __restrict__ delta,
@@ -145,24 +172,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
-    const int lc = tid & 7, lr = tid >> 3;
-    f32x4 rk[2], rv[2];
-    auto gload = [&](int kt) {
+    // K | V tiles by LDS-DMA (see dma_piece): one descriptor over this image's rows from its K segment on
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const i32x4 kv_rsrc = make_rsrc(kbase + row0 * ld, (Np - 1) * ld * 2 + (D + HD) * 2);
+    unsigned vk[2], vv[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int key = kt * TT + lr + 32 * i;
-            if (RAGGED) key = min(key, Np - 1);   // duplicates are masked below
-            const size_t off = (row0 + key) * ld + 8 * lc;
-            rk[i] = *(const f32x4*)(kbase + off);
-            rv[i] = *(const f32x4*)(vbase + off);
-        }
-    };
-    auto swrite = [&](int buf) {
+    for (int pc = 0; pc < 2; ++pc) {
+        vk[pc] = dma_voff(wv, pc, lane, ld * 2);
+        vv[pc] = vk[pc] + (unsigned)(D * 2);
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&lds[0][0][0];
+    auto stage = [&](int kt, int buf) {
+        const unsigned soff = (unsigned)(kt * TT * ld * 2);
+        const unsigned dst = lds_base + (unsigned)(buf * 2 * TT * HD * 2 + wv * 2048);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = lr + 32 * i;
-            *(f32x4*)&lds[buf][0][tile_off(key, lc)] = rk[i];
-            *(f32x4*)&lds[buf][1][tile_off(key, lc)] = rv[i];
+        for (int pc = 0; pc < 2; ++pc) {
+            dma_piece(dst + pc * 1024, vk[pc], kv_rsrc, soff);
+            dma_piece(dst + TT * HD * 2 + pc * 1024, vv[pc], kv_rsrc, soff);
         }
     };
     const int nkt = (Np + TT - 1) / TT;
@@ -173,41 +199,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
     }
     TileMasks lm;
     if (MW) lm.load(mrow);
-    gload(0);
-    swrite(0);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (MW) lm.wait();
-        gload(min(kt + 1, nkt - 1));
+        stage(min(kt + 1, nkt - 1), buf ^ 1);
         const bf16_t* Ks = lds[buf][0];
         const bf16_t* Vs = lds[buf][1];
-        f32x16 st[2], dp[2];
+        // one 32-key block at a time (S, dP -> dS -> dQ^T): 32 score registers live instead of 64, which is what lets three
+        // waves share a SIMD -- the other waves' MFMAs fill this wave's exponentials (profiles/r03_simd_overlap_probe.txt)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            f32x16 st, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                st[kb][r] = nlse;
-                dp[kb][r] = DROP ? 0.f : ndelta;
+                st[r] = nlse;
+                dp[r] = DROP ? 0.f : ndelta;
             }
             const int key = kb * 32 + li;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f32x4 kf = *(const f32x4*)&Ks[tile_off(key, 2 * s + lh)];
                 const f32x4 vf = *(const f32x4*)&Vs[tile_off(key, 2 * s + lh)];
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                                 __builtin_bit_cast(bf16x8, qf[s]), st[kb], 0, 0, 0);
-                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                                 __builtin_bit_cast(bf16x8, dof[s]), dp[kb], 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                             __builtin_bit_cast(bf16x8, qf[s]), st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                             __builtin_bit_cast(bf16x8, dof[s]), dp, 0, 0, 0);
             }
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
             unsigned pk[8];  // dS^T fragments: words 4 s + w = registers 8 s + 2 w, + 1
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const int k0 = kt * TT + kb * 32 + kappa(r, lh), k1 = k0 + 1;   // kappa(r + 1) = kappa(r) + 1 for even r
-                const float p0 = __builtin_amdgcn_exp2f(st[kb][r] * c), p1 = __builtin_amdgcn_exp2f(st[kb][r + 1] * c);
+                const float p0 = __builtin_amdgcn_exp2f(st[r] * c), p1 = __builtin_amdgcn_exp2f(st[r + 1] * c);
                 float d0, d1;
                 if (DROP) {
                     float m0, m1;
@@ -218,11 +243,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
                         m0 = drop_keep(dkey, (unsigned)k0, dr.thresh) ? dr.scale : 0.f;
                         m1 = drop_keep(dkey, (unsigned)k1, dr.thresh) ? dr.scale : 0.f;
                     }
-                    d0 = p0 * fmaf(dp[kb][r], m0, ndelta);
-                    d1 = p1 * fmaf(dp[kb][r + 1], m1, ndelta);
+                    d0 = p0 * fmaf(dp[r], m0, ndelta);
+                    d1 = p1 * fmaf(dp[r + 1], m1, ndelta);
                 } else {
-                    d0 = p0 * dp[kb][r];
-                    d1 = p1 * dp[kb][r + 1];
+                    d0 = p0 * dp[r];
+                    d1 = p1 * dp[r + 1];
                 }
                 if (RAGGED) {
                     d0 = k0 < Np ? d0 : 0.f;
@@ -240,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
             }
         }
         if (MW) lm.load(mrow + (size_t)min(kt + 1, nkt - 1) * 32);   // next tile's lane masks (see TileMasks)
-        swrite(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 have landed
         __syncthreads();
     }
     // ---- the CLS key: one vector update per query (ds is a scalar per lane) ----
@@ -283,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
 
 // ---------------------------------------------------------------------------------- dK, dV (patch keys)
 template <bool DROP, bool RAGGED, bool MW>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                    const bf16_t* __restrict__ dctx,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ delta,
@@ -316,47 +341,62 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
 
-    const int lc = tid & 7, lr = tid >> 3;
-    f32x4 rq[2], rd[2];
     float rs = 0.f, rdl = 0.f;
     unsigned rkey = 0;
     // mask words of this lane's KEY (both lane halves the same key): one word per 32-query group, bit = query.
     // Word position inside the key's 32-key block: 2 r + h with key = kappa(r, h).
     unsigned nw[2] = {0u, 0u};
-    const unsigned* mcol = nullptr;
+    // (one descriptor over this (image, head) pair's words, a 32-bit per-lane offset and a scalar tile offset: a 64-bit
+    // per-lane pointer here costs two registers the kernel does not have at three waves per SIMD)
+    const int mnb = Np >> 5;
+    auto mw_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)maskw, 0, 0, 0x00020000);
+    unsigned mw_voff = 0;
     if (MW) {
-        const int nb = Np >> 5;
         const int pos = 2 * ((li & 3) + 4 * (li >> 3)) + ((li >> 2) & 1);
-        mcol = maskw + ((size_t)((b * A + head) * nb) * nb + (nk >> 5)) * 32 + pos;   // + qg * nb * 32
+        mw_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(maskw + (size_t)((b * A + head) * mnb) * mnb * 32), 0,
+                                                    mnb * mnb * 32 * 4, 0x00020000);
+        mw_voff = (unsigned)(((nk >> 5) * 32 + pos) * 4);   // + qg * nb * 32 words
     }
-    auto gload = [&](int qt) {
+    // Q and dO tiles by LDS-DMA (see dma_piece): Q rows are 3 D apart (the q | k | v rows), dO rows D apart
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const i32x4 q_rsrc = make_rsrc(qkv + row0 * ld + head * HD, (Np - 1) * ld * 2 + HD * 2);
+    const i32x4 o_rsrc = make_rsrc(dctx + row0 * (size_t)D + head * HD, (Np - 1) * D * 2 + HD * 2);
+    unsigned vq[2], vo[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int q = qt * TT + lr + 32 * i;
-            if (RAGGED) q = min(q, Np - 1);
-            const size_t row = row0 + q;
-            rq[i] = *(const f32x4*)(qkv + row * ld + head * HD + 8 * lc);
-            rd[i] = *(const f32x4*)(dctx + row * (size_t)D + head * HD + 8 * lc);
-            if (MW) nw[i] = mcol[(size_t)(qt * 2 + i) * (Np >> 5) * 32];
+    for (int pc = 0; pc < 2; ++pc) {
+        vq[pc] = dma_voff(wv, pc, lane, ld * 2);
+        vo[pc] = dma_voff(wv, pc, lane, D * 2);
+    }
+    const auto lse_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(lse + stat0), 0, Np * 4, 0x00020000);
+    const auto dl_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(delta + stat0), 0, Np * 4, 0x00020000);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&lds[0][0][0];
+    // the tile's row constants and (MW) this key's mask words travel through registers as before: gload fetches them,
+    // swrite publishes the row constants next to the tile
+    auto gload = [&](int qt, int buf) {
+        const unsigned dst = lds_base + (unsigned)(buf * 2 * TT * HD * 2 + wv * 2048);
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            dma_piece(dst + pc * 1024, vq[pc], q_rsrc, (unsigned)(qt * TT * ld * 2));
+            dma_piece(dst + TT * HD * 2 + pc * 1024, vo[pc], o_rsrc, (unsigned)(qt * TT * D * 2));
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (MW) nw[i] = __builtin_amdgcn_raw_buffer_load_b32(mw_rsrc, mw_voff, (unsigned)((qt * 2 + i) * mnb * 32 * 4), 0);
         if (tid < TT) {
             const int q = qt * TT + tid;
             const bool ok = !RAGGED || q < Np;
-            const size_t si = stat0 + (ok ? q : Np - 1);
-            // a query beyond the last patch gets p = exp2(c * -inf) = 0 and contributes nothing
-            rs = ok ? -lse[si] * inv_c : -INFINITY;
-            rdl = ok ? -delta[si] : 0.f;
+            // a query beyond the last patch gets p = exp2(c * -inf) = 0 and contributes nothing (its row constants read as
+            // zeros: out of the descriptors' range)
+            const unsigned so = (unsigned)(qt * TT * 4);
+            const float l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, (unsigned)(tid * 4), so, 0));
+            const float dd = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dl_rsrc, (unsigned)(tid * 4), so, 0));
+            rs = ok ? -l * inv_c : -INFINITY;
+            rdl = ok ? -dd : 0.f;
             // the query's dropout key, hashed ONCE per query here instead of once per (query, key) element below
             if (DROP && !MW) rkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + q));
         }
     };
     auto swrite = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = lr + 32 * i;
-            *(f32x4*)&lds[buf][0][tile_off(q, lc)] = rq[i];
-            *(f32x4*)&lds[buf][1][tile_off(q, lc)] = rd[i];
-        }
         if (tid < TT) {
             stats[buf][0][tid] = rs;
             stats[buf][1][tid] = rdl;
@@ -364,33 +404,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
         }
     };
     const int nqt = (Np + TT - 1) / TT;
-    gload(0);
+    gload(0, 0);
     swrite(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int qt = 0; qt < nqt; ++qt) {
         const int buf = qt & 1;
         const unsigned cw[2] = {nw[0] >> (4 * lh), nw[1] >> (4 * lh)};   // bit 8 g4 + e = register 4 g4 + e of this lane half
-        gload(min(qt + 1, nqt - 1));
+        gload(min(qt + 1, nqt - 1), buf ^ 1);
         const bf16_t* Qs = lds[buf][0];
         const bf16_t* Os = lds[buf][1];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             // accumulator register 4 g4 + e <-> query qb * 32 + 8 g4 + 4 lh + e: four consecutive row constants per 16-byte read
-            f32x16 st, dp, dl;
-            unsigned rk16[16];
+            f32x16 st, dp;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int q0 = qb * 32 + 8 * g4 + 4 * lh;
                 const f32x4 a = *(const f32x4*)&stats[buf][0][q0];
-                const f32x4 d4 = *(const f32x4*)&stats[buf][1][q0];
-                f32x4 k4 = {0.f, 0.f, 0.f, 0.f};
-                if (DROP && !MW) k4 = *(const f32x4*)&stats[buf][2][q0];
+                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                if (!DROP) d4 = *(const f32x4*)&stats[buf][1][q0];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     st[4 * g4 + e] = a[e];
-                    dp[4 * g4 + e] = DROP ? 0.f : d4[e];
-                    dl[4 * g4 + e] = d4[e];
-                    rk16[4 * g4 + e] = __float_as_uint(k4[e]);
+                    dp[4 * g4 + e] = d4[e];      // DROP: the mask comes between dP and -delta, so dP starts at zero
                 }
             }
             const int q = qb * 32 + li;
@@ -405,27 +442,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
             }
             unsigned pp[8], pd[8];  // P~ and dS fragments (B operands), query = register index
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(st[r] * c), p1 = __builtin_amdgcn_exp2f(st[r + 1] * c);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                // DROP: -delta and the hashed dropout key of four queries are read from the tile's row constants HERE (one
+                // 16-byte broadcast read each) instead of living in 16 (+16) registers across the MFMAs above
+                f32x4 dl4 = {0.f, 0.f, 0.f, 0.f}, k4 = {0.f, 0.f, 0.f, 0.f};
                 if (DROP) {
-                    float m0, m1;
-                    if (MW) {   // 0 / -1 from the sign-extended bit, ANDed with the bits of 1 / (1 - p): two VALU ops
-                        // (asm: hipcc rewrites the intrinsic form into and + compare + select)
-                        const unsigned sb = __float_as_uint(dr.scale);
-                        int b0, b1;
-                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(b0) : "v"(cw[qb]), "n"(8 * (r >> 2) + (r & 3)));
-                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(b1) : "v"(cw[qb]), "n"(8 * (r >> 2) + (r & 3) + 1));
-                        m0 = __uint_as_float((unsigned)b0 & sb);
-                        m1 = __uint_as_float((unsigned)b1 & sb);
+                    const int q0 = qb * 32 + 8 * g4 + 4 * lh;
+                    dl4 = *(const f32x4*)&stats[buf][1][q0];
+                    if (!MW) k4 = *(const f32x4*)&stats[buf][2][q0];
+                }
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int r = 4 * g4 + 2 * w;
+                    const float p0 = __builtin_amdgcn_exp2f(st[r] * c), p1 = __builtin_amdgcn_exp2f(st[r + 1] * c);
+                    if (DROP) {
+                        float m0, m1;
+                        if (MW) {   // 0 / -1 from the sign-extended bit, ANDed with the bits of 1 / (1 - p): two VALU ops
+                            // (asm: hipcc rewrites the intrinsic form into and + compare + select)
+                            const unsigned sb = __float_as_uint(dr.scale);
+                            int b0, b1;
+                            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(b0) : "v"(cw[qb]), "n"(8 * (r >> 2) + (r & 3)));
+                            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(b1) : "v"(cw[qb]), "n"(8 * (r >> 2) + (r & 3) + 1));
+                            m0 = __uint_as_float((unsigned)b0 & sb);
+                            m1 = __uint_as_float((unsigned)b1 & sb);
+                        } else {
+                            m0 = drop_keep(__float_as_uint(k4[2 * w]), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                            m1 = drop_keep(__float_as_uint(k4[2 * w + 1]), (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                        }
+                        pp[r >> 1] = pack2_bf16(p0 * m0, p1 * m1);  // dropped P (what multiplied V in the forward)
+                        pd[r >> 1] = pack2_bf16(p0 * fmaf(dp[r], m0, dl4[2 * w]), p1 * fmaf(dp[r + 1], m1, dl4[2 * w + 1]));
                     } else {
-                        m0 = drop_keep(rk16[r], (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
-                        m1 = drop_keep(rk16[r + 1], (unsigned)nk, dr.thresh) ? dr.scale : 0.f;
+                        pp[r >> 1] = pack2_bf16(p0, p1);
+                        pd[r >> 1] = pack2_bf16(p0 * dp[r], p1 * dp[r + 1]);
                     }
-                    pp[r >> 1] = pack2_bf16(p0 * m0, p1 * m1);  // dropped P (what multiplied V in the forward)
-                    pd[r >> 1] = pack2_bf16(p0 * fmaf(dp[r], m0, dl[r]), p1 * fmaf(dp[r + 1], m1, dl[r + 1]));
-                } else {
-                    pp[r >> 1] = pack2_bf16(p0, p1);
-                    pd[r >> 1] = pack2_bf16(p0 * dp[r], p1 * dp[r + 1]);
                 }
             }
 #pragma unroll
@@ -442,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const bf16_t*
             }
         }
         swrite(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile qt + 1 have landed
         __syncthreads();
     }
     // ---- the CLS query: one vector update per key (p and ds are scalars per lane) ----
