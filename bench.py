@@ -36,8 +36,9 @@ from visiontransformer_amd.model import ViTSegmentationModel  # noqa: E402
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f32x3": 2500.0 / 3}  # x3: 3 fp16 MFMAs per product  # dense MFMA peaks, MI355X_MICROARCH.md
 KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
-    "f32": {"gemm_bias": "gemm_kernel<float, float, 0, 0, 0, 0, 0>", "gemm_gelu": "gemm_kernel<float, float, 0, 1, 0, 0, 0>",
-            "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0, 0>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
+    # fp32 linears with >= 128 tiles of 256x128: the persistent kernel gemm_f32p_kernel<EPI, DROP, AUX, INL> (csrc/gemm_f32p.hip)
+    "f32": {"gemm_bias": "gemm_f32p_kernel<0, false, false, true>", "gemm_gelu": "gemm_f32p_kernel<1, false, false, false>",
+            "gemm_resadd": "gemm_f32p_kernel<2, false, false, true>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
             "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 0>",
             "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
     # 16-bit operands: the 8-phase persistent kernel gemm_p8_kernel<T, OutT, EPI, TT> (csrc/gemm_p8.hip) whenever
@@ -47,7 +48,7 @@ KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
              "gemm_resadd": "gemm_p8_kernel<unsigned short, float, 2, 0>",
              "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
              "gemm_conv3": "gemm_bf16_large_kernel<unsigned short, float, 2, 3, 128>",
-             "attention": "attn_bf16_kernel<false, false, unsigned short> + attn_cls_bf16_kernel<unsigned short>"},
+             "attention": "attn_bf16_kernel<false, false, false, unsigned short> + attn_cls_bf16_kernel<unsigned short>"},
     "f32x3": {"gemm_bias": "gemm_kernel<float, float, 0, 0, 0, 0, 2>", "gemm_gelu": "gemm_kernel<float, float, 0, 1, 0, 0, 2>",
               "gemm_resadd": "gemm_kernel<float, float, 0, 2, 0, 0, 2>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 2>",
               "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 2>",
@@ -58,14 +59,14 @@ KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
             "gemm_resadd": "_ZN6vitseg14gemm_p8_kernelIDF16_fLi2ELi0EEEvNS_8GemmArgsE",
             "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
             "gemm_conv3": "_ZN6vitseg22gemm_bf16_large_kernelIDF16_fLi2ELi3ELi128EEEvNS_8GemmArgsE",
-            "attention": "_ZN6vitseg12_GLOBAL__N_116attn_bf16_kernelILb0ELb0EDF16_EEvPKtPtPfiiiNS_8DropArgsE + "
+            "attention": "_ZN6vitseg12_GLOBAL__N_116attn_bf16_kernelILb0ELb0ELb0EDF16_EEvPKtPtPfiiiNS_8DropArgsEPKj + "
                          "_ZN6vitseg12_GLOBAL__N_120attn_cls_bf16_kernelIDF16_EEvPKtPtPfiiiNS_8DropArgsE"},
     # training step (--mode train): kernel groups bracketed by the VITSEG_K_TRAIN_* scopes (csrc/vitseg_train.hip)
     "train_bf16": {"train_gemm_fwd": "gemm_p8_kernel<unsigned short, *, {0,1,2}, 0> (the four forward linears)",
                    "train_dgrad": "gemm_p8_kernel<unsigned short, *, {0,5}, 0> + transpose_bf16_kernel (activation gradients)",
                    "train_wgrad": "gemm_p8_kernel<unsigned short, float, 0, 1> + splitk_reduce_kernel (weight gradients)",
-                   "train_attn_fwd": "attn_bf16_kernel<true, false, unsigned short> + attn_cls_bf16_kernel<unsigned short>",
-                   "train_attn_bwd": "attn_bwd_dkv_bf16_kernel<true, false> + attn_bwd_dq_bf16_kernel<true, false> + "
+                   "train_attn_fwd": "attn_dropmask_kernel + attn_bf16_kernel<true, false, true, unsigned short> + attn_cls_bf16_kernel<unsigned short>",
+                   "train_attn_bwd": "attn_bwd_dkv_bf16_kernel<true, false, true> + attn_bwd_dq_bf16_kernel<true, false, true> + "
                                      "attn_bwd_cls_bf16_kernel<true> + attn_delta_bf16_kernel"},
     "train_f32": {"train_gemm_fwd": "gemm_kernel<float, float, 0, {0,1,2}, ...>", "train_dgrad": "gemm_kernel<float, float, ...> (W T-form)",
                   "train_wgrad": "gemm_kernel<float, float, ...> (both T-form, split-K)",
@@ -88,9 +89,9 @@ def algorithmic_bytes(precision, kind, cfg, batch):
 
 def pmc_traffic(precision, kernel_label, batch):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_pmc.sh bench_<prec> ... ->
-    tools/summarize_traffic.py -> profiles/r02_traffic_<prec>.json): counters cannot be read from inside this process,
+    tools/summarize_traffic.py -> profiles/r03_traffic_<prec>.json): counters cannot be read from inside this process,
     so the figure is the one rocprofv3 measured on this same command (batch 32).  None when no pass covers the run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_traffic_{precision}.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r03_traffic_{precision}.json")
     if batch != 32 or not os.path.exists(path):
         return None
     kernels = json.load(open(path))["kernels"]
@@ -144,29 +145,38 @@ def parity_vs(gpu_logits, gpu_mask, logits, mask):
 
 
 def bench_tiled(args, rank, world, dev, barrier):
-    """BASELINE configs[4]: ViT-L/16 seg inference on 1024x1024 inputs as four 512x512 tiles through an
-    image_size=512 model (build-defined tiling), fp16 operands by default; `--batch` 1024^2 images per
-    GPU (16 = the config's 128 over 8 GPUs).  Mask-only output, so the decoder tail writes 1 B/pixel."""
+    """BASELINE configs[4]: ViT-L/16 seg inference on 1024x1024 inputs, fp16 operands by default; `--batch` 1024^2 images
+    per GPU (16 = the config's 128 over 8 GPUs).  Mask-only output, so the decoder tail writes 1 B/pixel.
+    l16_1024_tiled: four 512x512 tiles through an image_size=512 model (build-defined tiling; N = 1025).
+    l16_1024_native: the image as ONE sequence of N = 4097 tokens through an image_size=1024 model (SURVEY 8d's
+    alternative: 3 738 GF per image, attention 44 % of it)."""
     from visiontransformer_amd.config import vit_large16
-    cfg = vit_large16(num_classes=2, image_size=512)
+    native = args.workload == "l16_1024_native"
+    S = 1024 if native else 512
+    cfg = vit_large16(num_classes=2, image_size=S)
     B = args.batch
     model = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
-                                 cfg.num_attention_heads, image_size=512,
+                                 cfg.num_attention_heads, image_size=S,
                                  precision={"f32": "fp32", "bf16": "bf16", "f16": "fp16"}[args.precision], device=dev).eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=1).items()})
-    tiles = torch.from_numpy(synth.make_images(cfg, 4 * B, seed=0, first_image=rank * 4 * B)).to(dev)
-    x = tiles.reshape(B, 2, 2, 3, 512, 512).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 1024, 1024).contiguous()
-    del tiles
+    if native:
+        x = torch.from_numpy(synth.make_images(cfg, B, seed=0, first_image=rank * B)).to(dev)
+        run = model.predict_mask
+    else:
+        tiles = torch.from_numpy(synth.make_images(cfg, 4 * B, seed=0, first_image=rank * 4 * B)).to(dev)
+        x = tiles.reshape(B, 2, 2, 3, 512, 512).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 1024, 1024).contiguous()
+        del tiles
+        run = model.predict_mask_tiled
     with torch.no_grad():
         for _ in range(args.warmup):
-            mask = model.predict_mask_tiled(x)
+            mask = run(x)
         torch.cuda.synchronize()
         barrier()
         _lib.profile_enable(True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            mask = model.predict_mask_tiled(x)
+            mask = run(x)
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -179,20 +189,23 @@ def bench_tiled(args, rank, world, dev, barrier):
         elapsed = float(t.item())
     if rank == 0:
         value = world * B * args.steps / elapsed
-        flops_img = 4.0 * cfg.forward_flops_per_image()
+        flops_img = (1.0 if native else 4.0) * cfg.forward_flops_per_image()
         peak = PEAK_TFLOPS[args.precision]
         mfma = {k: v for k, v in prof.items() if k.startswith("gemm") or k == "attention"}
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         d = mfma[dom]
         achieved = d["work"] / (d["ms"] * 1e-3) / 1e12
         print(json.dumps({
-            "metric": "images/sec (1024x1024 as 4 tiles of 512x512) ViT-L/16 seg",
+            "metric": "images/sec (1024x1024, one sequence of 4097 tokens) ViT-L/16 seg" if native
+                      else "images/sec (1024x1024 as 4 tiles of 512x512) ViT-L/16 seg",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"ViT-L/16 seg inference, {B} x 1024x1024 per GPU tiled 4 x 512x512, {args.precision}, "
+            "config": {"workload": f"ViT-L/16 seg inference, {B} x 1024x1024 per GPU "
+                                   f"{'native (N = 4097 tokens)' if native else 'tiled 4 x 512x512'}, {args.precision}, "
                                    f"uint8 mask output (BASELINE.json configs[4])", "batch_per_gpu": B,
-                       "global_batch": B * world, "tiles_per_step": 4 * B, "mask_positive_fraction": float(mask.float().mean()),
+                       "global_batch": B * world, "tiles_per_step": (1 if native else 4) * B,
+                       "mask_positive_fraction": float(mask.float().mean()),
                        "parallelism": f"batch-split x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
@@ -362,7 +375,7 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
                        "parallelism": f"data-parallel x{world}, bucketed gradient all-reduce ({collective_name(world)}) "
                                       f"overlapped with the backward"},
             # dominant kernel group of the step (largest summed device time): algorithmic FLOPs / hipEvent time on the
-            # launch stream; per-kernel times of the same command: profiles/r02_bench_train_*_kernel_stats.csv
+            # launch stream; per-kernel times of the same command: profiles/r03_bench_train_*_kernel_stats.csv
             "roofline": {"bound": "mfma", "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(dom_tflops / peak, 4), "traffic": None, "kernel": names.get(dom, dom),
                          "launches": d["launches"], "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
@@ -433,14 +446,15 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f32", "bf16", "f16", "f32x3"])
     ap.add_argument("--classes", type=int, default=2, help="segmentation classes (BASELINE configs use 2; the reference's "
                                                            "dataset has 17: the decoder tail then writes 17.8 MB/image)")
-    ap.add_argument("--workload", default="b16_512", choices=["b16_512", "l16_1024_tiled"],
-                    help="b16_512 = BASELINE configs[1] (default, the headline metric); l16_1024_tiled = configs[4]")
+    ap.add_argument("--workload", default="b16_512", choices=["b16_512", "l16_1024_tiled", "l16_1024_native"],
+                    help="b16_512 = BASELINE configs[1] (default, the headline metric); l16_1024_tiled = configs[4]; "
+                         "l16_1024_native = the same images as one 4097-token sequence each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode: dropout probability (reference 0.1)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "prep", "eval"],
                     help="train: one step = forward + CE + backward + gradient all-reduce + Adam (fp32)")
     args = ap.parse_args()
-    tiled = args.workload == "l16_1024_tiled"
+    tiled = args.workload in ("l16_1024_tiled", "l16_1024_native")
     if args.precision is None:
         args.precision = "f16" if tiled else "f32"
     if args.batch is None:

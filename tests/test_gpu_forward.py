@@ -82,6 +82,40 @@ def test_forward_matches_oracle_on_fresh_inputs():
         assert (tok[3 * Np + b] - ref_tok[b, 0]).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("precision,tol_logits,tol_mask", [("fp32", 2e-5, 0.0), ("fp16", 1e-3, 1e-3), ("bf16", 3e-2, 1.5e-2)])
+def test_forward_native_1024_sequence_of_4097_tokens(precision, tol_logits, tol_mask):
+    """BASELINE configs[4]'s alternative geometry: ViT-L/16 width (D 1024, 16 heads, I 3072) on a 1024x1024 input taken as
+    ONE sequence of N = 64 * 64 + 1 = 4097 tokens (model/CE/classes.py:224-238 with image_size 1024), one layer, batch 1,
+    against the oracle in fp64: last hidden state, logits and mask.  (The tiled run of the bench uses N = 1025.)"""
+    cfg = ViTSegConfig(2, 16, 1024, 1, 16, image_size=1024)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=33).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 1, seed=12))
+    torch.set_num_threads(16)
+    stages = {}
+    with torch.no_grad():
+        ref = O.forward(x.double(), {k: v.double() for k, v in sd.items()}, cfg, stages)
+    m = ViTSegmentationModel(2, 16, 1024, 1, 16, image_size=1024, precision=precision, device=DEV).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        mask, got = m.predict_mask(x.to(DEV), return_logits=True)
+    err = (got.cpu().double() - ref).abs().max().item()
+    tok = m.debug_buffer(1, _lib.BUF_TOKENS).view(-1, 1024).cpu().double()
+    Np = cfg.num_patches
+    assert Np == 4096 and tok.shape[0] == Np + 1
+    ref_tok = stages["layer_0"][0]
+    tok_err = max((tok[:Np] - ref_tok[1:]).abs().max().item(), (tok[Np] - ref_tok[0]).abs().max().item())
+    ref_mask = O.predict_mask(ref.float()).numpy()
+    mism = float((mask.cpu().numpy() != ref_mask).mean())
+    print(f"native 1024x1024 (N = 4097), {precision}: logits max-abs err {err:.3e}, token stream {tok_err:.3e}, "
+          f"mask mismatch {mism:.4%}")
+    assert err < tol_logits and tok_err < (5e-5 if precision == "fp32" else 0.25)
+    if precision == "fp32":   # identical wherever a 2 * err perturbation of the logits cannot flip the decision
+        stable = O.mask_stable(ref.float(), 2.0 * err + 1e-7).numpy()
+        assert ((mask.cpu().numpy() != ref_mask) & stable).sum() == 0 and (~stable).mean() < 2e-3
+    else:
+        assert mism <= tol_mask
+
+
 def test_batch_invariance_and_determinism():
     g = Golden("tiny16_224_c2")
     m = build(g)

@@ -10,6 +10,7 @@ import json
 import sys
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "f32"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 base = f"gpurun_out/pmc_bench_{prec}"
 acc = collections.defaultdict(lambda: {"fetch": [], "write": []})
 for kind in ("fetch", "write"):
@@ -41,6 +42,6 @@ for k, v in acc.items():
               "hbm_bytes_per_launch": rd + wr}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2; "
                      "read = 2 * FETCH_SIZE * 1024 (gfx950 wide-read correction), write = WRITE_SIZE * 1024",
-           "precision": prec, "kernels": out}, open(f"profiles/r02_traffic_{prec}.json", "w"), indent=1)
+           "precision": prec, "kernels": out}, open(f"profiles/{rnd}_traffic_{prec}.json", "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
     print(f"{k[:70]:70s} read {v['read_bytes_per_launch']/1e6:9.1f} MB  write {v['write_bytes_per_launch']/1e6:9.1f} MB  x{v['launches_sampled']}")

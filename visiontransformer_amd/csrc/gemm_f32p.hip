@@ -282,19 +282,26 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
             asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:128"
                          : "=&v"(nb0), "=&v"(nb1) : "v"(bo), "s"(bp) : "memory");
         }
+// (one DMA piece at a time between clusters of 8 MFMAs: issuing a piece costs ~60 cycles, what ONE 64-cycle MFMA covers;
+// two in a row leave the matrix pipe idle for the second)
 #define F32P_GROUP(slot, jn, D0, D1, D2, D3)                                    \
         read_frags(roff, jn, (slot) ^ 1);                                       \
         F32P_SB();                                                              \
         mfma8(slot, 0);                                                         \
         F32P_SB();                                                              \
-        D0; D1;                                                                 \
+        D0;                                                                     \
         F32P_SB();                                                              \
         mfma8(slot, 1);                                                         \
         F32P_SB();                                                              \
-        D2; D3;                                                                 \
+        D1;                                                                     \
         F32P_SB();                                                              \
         mfma8(slot, 2);                                                         \
+        F32P_SB();                                                              \
+        D2;                                                                     \
+        F32P_SB();                                                              \
         mfma8(slot, 3);                                                         \
+        F32P_SB();                                                              \
+        D3;                                                                     \
         F32P_SB();
         F32P_GROUP(0, 1, dma_a(dbase, 0), dma_a(dbase, 1), dma_a(dbase, 2), dma_a(dbase, 3))
         F32P_GROUP(1, 2, dma_a(dbase, 4), dma_a(dbase, 5), dma_a(dbase, 6), dma_a(dbase, 7))
@@ -371,26 +378,21 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
                 read_frags(nroff, 0, 0);
             }
             F32P_SB();
-            // the sub-tile's 16 MFMAs, DMA pieces of step G + 2 in the middle (2 per sub-tile, sub-tiles 0..5)
+            // the sub-tile's 16 MFMAs with the DMA pieces of step G + 2 between them, one at a time (2 per sub-tile,
+            // sub-tiles 0..5)
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 c = zero;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(gw[buf][j][e], ga[buf][j][e], c, 0, 0, 0);
-            F32P_SB();
-            if (t < 4) {
-                dma_a(dbase, 2 * t);
-                dma_a(dbase, 2 * t + 1);
-            } else if (t < 6) {
-                dma_w(dbase, 2 * (t - 4));
-                dma_w(dbase, 2 * (t - 4) + 1);
+                if (j == 0 || j == 2) {
+                    const int pc = 2 * t + (j >> 1);   // pieces 0..7 of A, then 0..3 of W
+                    F32P_SB();
+                    if (t < 4) dma_a(dbase, pc); else if (t < 6) dma_w(dbase, pc - 8);
+                    F32P_SB();
+                }
             }
-            F32P_SB();
-#pragma unroll
-            for (int j = 2; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(gw[buf][j][e], ga[buf][j][e], c, 0, 0, 0);
             acc[mt][nt] = c;
             // finish and store the parked sub-tile of the previous tile (VALU + 4 stores under the MFMAs above)
             const int row0 = pm0 + wr * 128 + mt * 32, col0 = pn0 + wc * 64 + nt * 32;
