@@ -161,30 +161,6 @@ __device__ __forceinline__ float wave_max(float v) {
 // exact (erf) GELU, activations.py:78-83
 __device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
 
-// The same function without control flow: libm's erff (ROCm device library, __ocml_erf_f32) branches on |x| < 1; both of its
-// polynomials are evaluated here with the library's coefficients and operation order and one select picks the result,
-// so the value is BIT-IDENTICAL to erff(x) for every input (tools/probes/erff_nb_check.hip sweeps all 2^32 floats)
-// while the instruction stream is straight-line code the scheduler can place between MFMAs (gemm_f32p.hip).
-__device__ __forceinline__ float erff_nb(float x) {
-    const float ax = fabsf(x), t = x * x;
-    float ps = fmaf(t, __uint_as_float(0xba1345e1u), __uint_as_float(0x3ba10414u));
-    ps = fmaf(t, ps, __uint_as_float(0xbcdac9b8u));
-    ps = fmaf(t, ps, __uint_as_float(0x3de703beu));
-    ps = fmaf(t, ps, __uint_as_float(0xbec09330u));
-    ps = fmaf(t, ps, __uint_as_float(0x3e0375d0u));
-    const float small = fmaf(ax, ps, ax);
-    float pb = fmaf(ax, __uint_as_float(0x378e98abu), __uint_as_float(0xb9c68948u));
-    pb = fmaf(ax, pb, __uint_as_float(0x3b7cd369u));
-    pb = fmaf(ax, pb, __uint_as_float(0xbcc618b2u));
-    pb = fmaf(ax, pb, __uint_as_float(0x3dda74e4u));
-    pb = fmaf(ax, pb, __uint_as_float(0x3f228afdu));
-    pb = fmaf(ax, pb, __uint_as_float(0x3e03c728u));
-    pb = fmaf(ax, pb, ax);
-    const float big = 1.0f - expf(-pb);
-    return copysignf(ax < 1.0f ? small : big, x);
-}
-__device__ __forceinline__ float gelu_erf_nb(float u) { return 0.5f * u * (1.0f + erff_nb(u * 0.70710678118654752440f)); }
-
 // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
 __device__ __forceinline__ float gelu_erf_grad(float u) {
     const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
