@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 have landed
         __syncthreads();
     }
+    if (MW) lm.wait();   // the last iteration's mask load is still writing its 64 SGPRs: nothing may reuse them before it lands
 
     // ---- normalise and store: lane holds d = 32 dt + 8 g4 + 4 lh + e of its query ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

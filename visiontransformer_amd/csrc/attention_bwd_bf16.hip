@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 have landed
         __syncthreads();
     }
+    if (MW) lm.wait();   // the last iteration's mask load is still writing its 64 SGPRs: nothing may reuse them before it lands
     // ---- the CLS key: one vector update per query (ds is a scalar per lane) ----
     {
         f32x4 kc[4], vc[4];
