@@ -1,0 +1,67 @@
+// Where do the idle matrix-pipe cycles of csrc/gemm_f32p.hip go?  Standalone harness: includes a (possibly patched) copy of
+// the kernel source (F32P_SRC) and times it on the model's shapes.  tools/probes/f32p_where.sh builds the variants:
+// the product kernel, and copies with the barrier / the DMA / the fragment reads removed (results are garbage there; only
+// the time matters).
+#include <hip/hip_runtime.h>
+#pragma clang diagnostic ignored "-Wunused-value"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include F32P_SRC
+
+namespace vitseg {
+int hip_fail(hipError_t e, const char* what) {
+    fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e));
+    return 1;
+}
+void set_error(const char* fmt, ...) { fprintf(stderr, "%s\n", fmt); }
+}   // namespace vitseg
+
+__global__ void fill_kernel(float* x, size_t n, unsigned seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        x[i] = ((int)(h & 0xffff) - 32768) * (scale / 32768.f);
+    }
+}
+
+int main(int argc, char** argv) {
+    // weight scale: 0.05 puts ~99 % of the fc1 pre-activations below |x| = 1.41 (erff's cheap side); 0.15 spreads them over both
+    const float wscale = argc > 1 ? (float)atof(argv[1]) : 0.05f;
+    const int M = 32768;
+    struct Shape { const char* name; int N, K, epi; } shapes[] = {
+        {"qkv", 2304, 768, vitseg::EPI_BIAS}, {"fc1+gelu", 3072, 768, vitseg::EPI_GELU}, {"fc1 (bias)", 3072, 768, vitseg::EPI_BIAS},
+        {"fc2+res", 768, 3072, vitseg::EPI_RESADD}, {"o_proj+res", 768, 768, vitseg::EPI_RESADD}};
+    float *A, *W, *b, *C;
+    hipMalloc(&A, (size_t)M * 3072 * 4);
+    hipMalloc(&W, (size_t)3072 * 3072 * 4);
+    hipMalloc(&b, 3072 * 4);
+    hipMalloc(&C, (size_t)M * 3072 * 4);
+    // random operands: the matrix pipe's power draw (and with it the clock) depends on the data
+    fill_kernel<<<2048, 256>>>(A, (size_t)M * 3072, 1u, 1.f);
+    fill_kernel<<<2048, 256>>>(W, (size_t)3072 * 3072, 2u, wscale);
+    fill_kernel<<<16, 256>>>(b, 3072, 3u, 0.1f);
+    fill_kernel<<<2048, 256>>>(C, (size_t)M * 3072, 4u, 1.f);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (const Shape& s : shapes) {
+        vitseg::GemmArgs a = {};
+        a.A = A; a.W = W; a.bias = b; a.R = s.epi == vitseg::EPI_RESADD ? C : nullptr; a.C = C;
+        a.M = M; a.N = s.N; a.K = s.K; a.lda = s.K; a.ldc = s.N; a.ldw = s.K;
+        float best = 1e9f;
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            hipEventRecord(e0, 0);
+            for (int i = 0; i < 10; ++i)
+                if (vitseg::launch_gemm_f32p(a, s.epi, 0)) return 1;
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rnd && ms / 10 < best) best = ms / 10;
+        }
+        printf("%-12s %8.1f us  %6.1f TFLOP/s\n", s.name, best * 1e3, 2.0 * M * s.N * s.K / (best * 1e-3) * 1e-12);
+    }
+    return 0;
+}

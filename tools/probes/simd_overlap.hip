@@ -18,7 +18,11 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+#ifdef F32MFMA   // the fp32 matrix instruction (64 cycles; 8 per iteration = 512 matrix cycles): does IT leave the vector ALU free?
+#define MFMA(acc) "v_mfma_f32_32x32x2_f32 %" #acc ", %18, %19, %" #acc "\n\t"
+#else
 #define MFMA(acc) "v_mfma_f32_32x32x16_bf16 %" #acc ", %16, %17, %" #acc "\n\t"
+#endif
 #if VOP == 0
 #define V1(r) "v_fma_f32 %" #r ", %" #r ", %18, %19\n\t"
 #define VPER 6

@@ -2,8 +2,9 @@
 # builds and runs tools/probes/simd_overlap.hip on the GPU box: wall times, then one rocprofv3 --pmc pass for the counter view
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-for vop in 0 1; do
-  hipcc --offload-arch=gfx950 -O3 -DVOP=$vop tools/probes/simd_overlap.hip -o gpurun_out/simd_overlap$vop 2>/dev/null || exit 1
+for vop in ${SIMD_OVERLAP_VARIANTS:-0 1 f32}; do
+  extra=""; v=$vop; if [ $vop = f32 ]; then extra="-DF32MFMA"; v=0; echo "== fp32 MFMA (v_mfma_f32_32x32x2_f32), 48 v_fma_f32"; fi
+  hipcc --offload-arch=gfx950 -O3 -DVOP=$v $extra tools/probes/simd_overlap.hip -o gpurun_out/simd_overlap$vop 2>/dev/null || exit 1
   gpurun_out/simd_overlap$vop
   rm -rf gpurun_out/simd_overlap_pmc$vop
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv \

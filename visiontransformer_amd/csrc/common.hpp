@@ -161,6 +161,38 @@ __device__ __forceinline__ float wave_max(float v) {
 // exact (erf) GELU, activations.py:78-83
 __device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
 
+// The same function without control flow: libm's erff (ROCm device library, __ocml_erf_f32) branches on |x| < 1, and a
+// wave whose lanes disagree runs both sides plus the branch bookkeeping.  Both polynomials are evaluated here with the
+// library's coefficients and operation order and one select picks the result: BIT-IDENTICAL to erff(x) for every input
+// (tools/probes/erff_nb_check.hip sweeps all 2^32 floats), straight-line code the scheduler can place between MFMAs.
+__device__ __forceinline__ float erff_nb(float x) {
+#pragma clang fp contract(off)   // every fused multiply-add below is spelled out; ph - e must stay a subtraction
+    const float ax = fabsf(x), t = x * x;
+    float ps = fmaf(t, __uint_as_float(0xba1345e1u), __uint_as_float(0x3ba10414u));
+    ps = fmaf(t, ps, __uint_as_float(0xbcdac9b8u));
+    ps = fmaf(t, ps, __uint_as_float(0x3de703beu));
+    ps = fmaf(t, ps, __uint_as_float(0xbec09330u));
+    ps = fmaf(t, ps, __uint_as_float(0x3e0375d0u));
+    const float small = fmaf(ax, ps, ax);
+    float pb = fmaf(ax, __uint_as_float(0x378e98abu), __uint_as_float(0xb9c68948u));
+    pb = fmaf(ax, pb, __uint_as_float(0x3b7cd369u));
+    pb = fmaf(ax, pb, __uint_as_float(0xbcc618b2u));
+    pb = fmaf(ax, pb, __uint_as_float(0x3dda74e4u));
+    pb = fmaf(ax, pb, __uint_as_float(0x3f228afdu));
+    pb = fmaf(ax, pb, __uint_as_float(0x3e03c728u));
+    pb = fmaf(ax, pb, ax);
+    // 1 - exp(-pb) with the library's expf steps (49-bit log2 e product, rndne, v_exp_f32, ldexp) minus its two range
+    // guards: -pb is clamped at -104 instead (exp underflows to less than half an ulp of 1 either way), and a NaN takes
+    // the `small` side of the select, which propagates it
+    const float nx = fmaxf(-pb, -104.0f);
+    const float ph = nx * 0x1.715476p+0f;
+    const float pl = fmaf(nx, 0x1.4ae0bep-26f, fmaf(nx, 0x1.715476p+0f, -ph));
+    const float e = rintf(ph);
+    const float big = 1.0f - ldexpf(__builtin_amdgcn_exp2f(ph - e + pl), (int)e);
+    return copysignf(ax >= 1.0f ? big : small, x);
+}
+__device__ __forceinline__ float gelu_erf_nb(float u) { return 0.5f * u * (1.0f + erff_nb(u * 0.70710678118654752440f)); }
+
 // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
 __device__ __forceinline__ float gelu_erf_grad(float u) {
     const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));

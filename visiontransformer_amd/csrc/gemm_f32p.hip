@@ -43,8 +43,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // DROP: hidden dropout on the residual branch compiled in (fp32 training forward)
 // AUX: the GELU epilogue also stores the pre-activation (fp32 training forward)
-// INL: a finished tile is written under the first K step of the block's next tile (kstep_first; not for GELU, whose
-//      ~36 VALU per element do not fit behind one step's MFMAs)
+// INL: a finished tile is written under the first K step of the block's next tile (kstep_first; GELU's ~32 VALU per
+//      value are 4 x what that step's MFMAs hide, so the step is VALU-bound there and takes about two plain steps)
 template <int EPI, bool DROP, bool AUX, bool INL>
 __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ring | per-wave slabs
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
     auto epi_value = [&](float x, float& pre, int grow, int gcol) {
         if (EPI == EPI_GELU) {
             pre = x;                            // saved pre-activation (fp32 training)
-            x = gelu_erf(x);
+            x = gelu_erf_nb(x);                // = gelu_erf(x) bit for bit, without its branch
         }
         if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
         if (EPI == EPI_RESADD && DROP)
@@ -282,12 +282,28 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
             asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:128"
                          : "=&v"(nb0), "=&v"(nb1) : "v"(bo), "s"(bp) : "memory");
         }
+// the group's 6 fragment reads (for the NEXT group) go one per MFMA into the first cluster: issued in a row in front of
+// it they outlast the one MFMA that is in flight (-3 % measured, tools/probes/f32p_where.sh)
+#define F32P_READS_UNDER_MFMAS()                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0)
 // (one DMA piece at a time between clusters of 8 MFMAs: issuing a piece costs ~60 cycles, what ONE 64-cycle MFMA covers;
 // two in a row leave the matrix pipe idle for the second)
 #define F32P_GROUP(slot, jn, D0, D1, D2, D3)                                    \
         read_frags(roff, jn, (slot) ^ 1);                                       \
-        F32P_SB();                                                              \
         mfma8(slot, 0);                                                         \
+        F32P_READS_UNDER_MFMAS();                                               \
         F32P_SB();                                                              \
         D0;                                                                     \
         F32P_SB();                                                              \
@@ -318,8 +334,9 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_barrier();
         F32P_SB();
         read_frags(nroff, 0, 0);
-        F32P_SB();
         mfma8(1, 0);
+        F32P_READS_UNDER_MFMAS();
+        F32P_SB();
         mfma8(1, 1);
         mfma8(1, 2);
         mfma8(1, 3);
@@ -362,7 +379,6 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int mt = t >> 1, nt = t & 1, buf = t & 1;
-            if (t < 7) read_sub(t + 1, buf ^ 1);
             if (EPI == EPI_RESADD && t < 7) load_r(t + 1, buf ^ 1);
             f32x4 sv[4];
             park(acc[mt][nt], sv);
@@ -372,7 +388,9 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
                 if (EPI == EPI_RESADD)
                     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(rv[1][0]), "+v"(rv[1][1]), "+v"(rv[1][2]), "+v"(rv[1][3]) :: "memory");
                 else
-                    asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");   // 12 DMA + 28 stores issued by this step
+                    // 12 DMA + 28 stores issued by this step (GELU with the saved pre-activation: 56 stores -- the count,
+                    // capped by the 6-bit counter, then also waits for this step's oldest 28, which are long done)
+                    asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 F32P_SB();
                 read_frags(nroff, 0, 0);
@@ -384,8 +402,38 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
             f32x16 c = zero;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                // the next sub-tile's 8 fragment reads go one per MFMA under chunk pairs 1 and 2
+                if (j == 1 && t < 7) read_sub(t + 1, buf ^ 1);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(gw[buf][j][e], ga[buf][j][e], c, 0, 0, 0);
+                if (EPI == EPI_GELU) {
+                    // GELU: ~32 VALU per value, 4 x the issue slots one MFMA leaves -- row group j of the parked sub-tile
+                    // is finished beside chunk pair j's 4 MFMAs (32 VALU behind each): the step takes about twice its
+                    // MFMA time, against a whole epilogue's ~2.8 steps when nothing overlaps
+                    const int grow = pm0 + wr * 128 + mt * 32 + 8 * j + rrow, gcol = pn0 + wc * 64 + nt * 32 + c8 * 4;
+                    f32x4 pre4, out4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pre = 0.f;
+                        out4[e] = epi_value(sv[j][e] + (nt ? pb1[e] : pb0[e]), pre, grow, gcol + e);
+                        pre4[e] = pre;
+                    }
+                    const size_t o = (size_t)grow * p.ldc + gcol;
+                    if (AUX) *(f32x4*)((float*)p.aux + o) = pre4;
+                    *(f32x4*)((float*)p.C + o) = out4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (j == 2 && t < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
+                    }
+                } else if (j == 2 && t < 7) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
                 if (j == 0 || j == 2) {
                     const int pc = 2 * t + (j >> 1);   // pieces 0..7 of A, then 0..3 of W
                     F32P_SB();
@@ -407,7 +455,7 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
             }
             char* cb = (char*)((float*)p.C + (size_t)row0 * p.ldc + col0);
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
+            for (int ps = 0; ps < 4 && EPI != EPI_GELU; ++ps) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float pre = 0.f;
@@ -479,8 +527,8 @@ int launch_f32p_one_i(const GemmArgs& a, hipStream_t s) {
 template <int EPI, bool DROP = false, bool AUX = false>
 int launch_f32p_one(const GemmArgs& a, hipStream_t s) {
     static const bool noinl = getenv("VITSEG_F32P_NOINL") != nullptr;   // experiments: every epilogue at its tile's end
-    if (EPI == EPI_GELU || noinl || a.K < 4 * FK) return launch_f32p_one_i<EPI, DROP, AUX, false>(a, s);
-    return launch_f32p_one_i<EPI, DROP, AUX, EPI != EPI_GELU>(a, s);
+    if (noinl || a.K < 4 * FK) return launch_f32p_one_i<EPI, DROP, AUX, false>(a, s);
+    return launch_f32p_one_i<EPI, DROP, AUX, true>(a, s);
 }
 
 }  // namespace
