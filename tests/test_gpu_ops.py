@@ -186,7 +186,9 @@ FMT = {"bf16": (torch.bfloat16, 2 ** -8, "vitseg_op_linear_bf16", "vitseg_op_att
 
 @pytest.mark.parametrize("M,N,K,epi", [(128, 128, 64, 0), (257, 192, 128, 0), (788, 576, 192, 1), (1025, 768, 3072, 2),
                                        (2050, 2304, 768, 0), (33, 96, 64, 2), (130, 3072, 768, 1),
-                                       (4129, 768, 768, 0), (4608, 384, 192, 1), (5000, 200, 3072, 2), (8224, 2304, 768, 0)])
+                                       (4129, 768, 768, 0), (4608, 384, 192, 1), (5000, 200, 3072, 2), (8224, 2304, 768, 0),
+                                       (16584, 2304, 768, 0),   # 585 tiles: three per block of gemm_h16p.hip, ragged last row tile
+                                       (66048, 768, 512, 0)])   # 774 tiles of a short reduction (8 K steps per tile)
 @pytest.mark.parametrize("fmt", ["bf16", "fp16"])
 def test_linear_bf16(M, N, K, epi, fmt):
     dt, ulp, fn, _ = FMT[fmt]

@@ -1,0 +1,50 @@
+#!/bin/bash
+# builds tools/probes/p8_where.hip against the product kernel and against patched copies (gpurun_out/p8_where/) and prints
+# one timing block per variant.  Run on the GPU box:  bash tools/probes/p8_where.sh     (P8_WHERE_VARIANTS="base noepi")
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+out=gpurun_out/p8_where
+mkdir -p $out
+python3 - visiontransformer_amd/csrc/gemm_p8.hip "$out" <<'PY'
+import os, sys
+src, out = sys.argv[1], sys.argv[2]
+s = open(src).read().replace('#include "kernels.hpp"', '#include "%s/visiontransformer_amd/csrc/kernels.hpp"' % os.getcwd())
+def w(tag, t):
+    open("%s/%s.hip" % (out, tag), "w").write(t)
+def rep(t, a, b):
+    assert a in t, a
+    return t.replace(a, b)
+w("base", s)
+w("h16p", open("visiontransformer_amd/csrc/gemm_h16p.hip").read().replace('#include "kernels.hpp"', '#include "%s/visiontransformer_amd/csrc/kernels.hpp"' % os.getcwd()))
+if os.path.exists("tools/probes/tmp_old_p8.hip"):   # an untracked copy of an earlier version, for A/B on the same box
+    w("old", open("tools/probes/tmp_old_p8.hip").read().replace('#include "kernels.hpp"', '#include "%s/visiontransformer_amd/csrc/kernels.hpp"' % os.getcwd()))
+# the accumulators must stay live (a kernel whose MFMA results are unused loses its MFMAs): sum them and compare
+noepi = rep(s, "            epilogue(tc_cur);\n", """            { float t = 0.f;
+              for (int mt = 0; mt < 8; ++mt) for (int nt = 0; nt < 4; ++nt) for (int r = 0; r < 4; ++r) t += acc[mt][nt][r];
+              if (t == 1.2345f) ((float*)p.C)[0] = t; }
+""")
+# epilogue without the LDS round trip (values land in the wrong places; the store pattern is the product's)
+nolds = rep(s, """            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private: no barrier needed
+""", "")
+nolds = rep(nolds, """                    const f32x4 t = *(const f32x4*)(stage + row * 64 + ((((rcol >> 2) + c4) ^ row) << 2));
+""", """                    const f32x4 t = acc[mt][(i * (CPL / 4) + c4) & 3];
+""")
+nolds = rep(nolds, """                *(f32x4*)(stage + l15 * 64 + (((nt * 4 + lq) ^ l15) << 2)) = acc[mt][nt];
+""", """                ;
+""")
+w("epi_nolds", nolds)
+w("noepi", noepi)
+nostore = rep(s, "                    if (grow < p.M) {\n                        if (EPI == EPI_GELU && p.aux) *(uint4*)((T*)p.aux + o) = ha;\n                        *(uint4*)(Cbase + o) = h;\n                    }",
+              "                    if (grow < 0) {\n                        if (EPI == EPI_GELU && p.aux) *(uint4*)((T*)p.aux + o) = ha;\n                        *(uint4*)(Cbase + o) = h;\n                    }")
+nostore = rep(nostore, "if (grow < p.M) *(f32x4*)((float*)Cbase + o)", "if (grow < 0) *(f32x4*)((float*)Cbase + o)")
+w("nostore", nostore)
+nobar = rep(noepi, "        __builtin_amdgcn_s_barrier();         \\\n", "        ;         \\\n")
+w("noepi_nobarrier", nobar)
+nodma = rep(noepi, '"s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds"', '""')
+w("noepi_nodma", nodma)
+PY
+for v in ${P8_WHERE_VARIANTS:-base noepi nostore epi_nolds noepi_nobarrier noepi_nodma}; do
+  p8src=$v; hsrc=h16p
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DP8_SRC="\"$PWD/$out/$p8src.hip\"" -DH16P_SRC="\"$PWD/$out/$hsrc.hip\"" tools/probes/p8_where.hip -o $out/$v 2> $out/$v.err || { cat $out/$v.err; exit 1; }
+  echo "== $v"
+  if [ -z "$P8_WHERE_BUILD_ONLY" ]; then $out/$v $P8_WHERE_M || exit 1; fi
+done

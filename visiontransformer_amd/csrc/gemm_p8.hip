@@ -564,6 +564,7 @@ static int launch_p8_t(GemmArgs a, int epi, hipStream_t s) {
 }
 
 int launch_gemm_p8(const GemmArgs& a, int epi, hipStream_t s, bool f16) {
+    if (gemm_h16p_applies(a, epi)) return launch_gemm_h16p(a, s, f16);   // bias epilogue, short K (VITSEG_NO_H16P=1: this file's kernel)
     return f16 ? launch_p8_t<f16_t>(a, epi, s) : launch_p8_t<bf16_t>(a, epi, s);
 }
 

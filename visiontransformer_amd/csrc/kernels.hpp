@@ -80,6 +80,10 @@ int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s, bool 
 int gemm_p8_rounds(int M, int N);
 bool gemm_p8_applies(const GemmArgs& a, int epi);
 int launch_gemm_p8(const GemmArgs& a, int epi, hipStream_t s, bool f16);
+// 16-bit persistent kernel for the bias epilogue with a short reduction (gemm_h16p.hip): one wave per SIMD, 128 x 128 per
+// wave, a finished tile leaves under the next tile's first K step.
+bool gemm_h16p_applies(const GemmArgs& a, int epi);
+int launch_gemm_h16p(const GemmArgs& a, hipStream_t s, bool f16);
 // persistent 256x128 fp32 kernel for the large plain linear layers of the parity path (gemm_f32p.hip)
 bool gemm_f32p_applies(const GemmArgs& a, int epi);
 int launch_gemm_f32p(const GemmArgs& a, int epi, hipStream_t s);
