@@ -163,6 +163,31 @@ def test_batch_shard_gradient_equivalence():
     assert (full - halves).abs().max().item() <= 1e-6 * max(1.0, full.abs().max().item())
 
 
+def test_gradient_buffer_is_handed_over_not_cloned():
+    """The buffer vitseg_backward writes becomes `arena.grad` itself (no arena-sized clone per step): with
+    zero_grad(set_to_none=True) between steps the same storage serves every step; while a gradient is pending the next
+    backward gets a temporary and is ADDED (accumulation), and the logits path behaves the same."""
+    g = Golden("base16w_l2_224_c2_train")
+    lm = _build(g).train()
+    m = lm.model
+    m.dropout = 0.0
+    x, y = g.images().to(DEV), lm._resize_target(g.targets().to(DEV), (224, 224))
+    m.arena.grad = None
+    m.ce_loss(x, y).backward()
+    p0, g0 = m.arena.grad.data_ptr(), m.arena.grad.clone()
+    assert p0 == m._grad_buf.data_ptr()
+    m.arena.grad = None                       # zero_grad(set_to_none=True)
+    m.ce_loss(x, y).backward()
+    assert m.arena.grad.data_ptr() == p0 and torch.equal(m.arena.grad, g0)
+    m.ce_loss(x, y).backward()                # gradient pending: accumulate, the installed buffer is not overwritten
+    assert m.arena.grad.data_ptr() == p0 and torch.equal(m.arena.grad, g0 + g0)
+    m.arena.grad = None
+    logits = m(x)                             # autograd path through the logits
+    torch.nn.functional.cross_entropy(logits, y.long()).backward()
+    assert m.arena.grad.data_ptr() == p0
+    assert (m.arena.grad - g0).abs().max().item() <= 2e-6 * max(1.0, g0.abs().max().item())
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_overlapped_bucket_allreduce_inside_backward(precision):
     """Section 8(e): vitseg_backward records one event per gradient bucket; the host queues one RCCL all-reduce

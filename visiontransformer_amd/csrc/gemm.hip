@@ -1110,12 +1110,14 @@ int launch_large(GemmArgs a, hipStream_t s) {
     if (!a.gn) a.gn = env_gn();
     const int tiles = ((a.M + LBM - 1) / LBM) * ((a.N + LBN - 1) / LBN);
     const size_t smem = (size_t)(LBN == 128 ? 3 : 2) * (LBM + LBN) * BKF * sizeof(float);  // 144 / 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
+    int dev = 0;
+    static bool attr_set[64] = {};   // the attribute is per device
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_large)");
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL((gemm_bf16_large_kernel<T, OutT, AMODE, EPI, LBN>), dim3(tiles), dim3(512), smem, s, a);
     VITSEG_LAUNCH_CHECK("gemm_bf16_large");

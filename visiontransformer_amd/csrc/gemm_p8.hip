@@ -517,15 +517,16 @@ bool gemm_p8_applies(const GemmArgs& a, int epi) {
            (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESADD || epi == EPI_DGELU);
 }
 
-static int p8_num_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
+static int p8_num_cus() {   // per device: a process may drive several
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    static int ncu[64] = {};
+    if (!ncu[dev]) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    return ncu;
+    return ncu[dev];
 }
 
 // rounds of the persistent grid an NT launch with M rows takes (one 256 x 256 tile per CU and round)
@@ -536,11 +537,13 @@ int gemm_p8_rounds(int M, int N) {
 
 template <typename T, typename OutT, int EPI, int TT>
 static int launch_p8_one(GemmArgs a, int items, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    int dev = 0;
+    static bool attr_set[64] = {};   // the attribute is per device
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_p8_kernel<T, OutT, EPI, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_p8)");
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int ncu = p8_num_cus();
     const int grid = items < ncu ? items : ncu;

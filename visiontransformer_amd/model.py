@@ -39,14 +39,15 @@ class _LogitsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         grads, _ = ctx.model._backward(ctx.x, grad_logits=dlogits.to(torch.float32).contiguous(), drop=ctx.drop)
-        ctx.model._release_grad_buffer(grads)   # autograd owns it from here (as arena.grad, or summed into it)
-        return grads, None, None
+        return ctx.model._deliver_grad(grads), None, None
 
 
 class _CELossFn(torch.autograd.Function):
     """Fused CE: forward + loss + backward in one go (no [B,C,S,S] logits tensor is returned).  With `grad_scale` the
     factor is folded into the CE gradient at its source (vitseg_backward's loss_scale) and the upstream gradient of the
-    returned loss is taken to be 1: no arena-sized multiply, no second arena-sized temporary."""
+    returned loss is taken to be 1: no arena-sized multiply.  The gradient is delivered by `_deliver_grad` (installed as
+    `arena.grad` or added to it), not returned to autograd: AccumulateGrad would clone an arena-sized tensor it cannot
+    steal (the model keeps a reference to its persistent buffer)."""
 
     @staticmethod
     def forward(ctx, arena, model, x, target, grad_scale):
@@ -59,8 +60,10 @@ class _CELossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss):
-        ctx.model._release_grad_buffer(ctx.grads)   # autograd owns it from here (as arena.grad, or summed into it)
-        return (ctx.grads if ctx.prescaled else ctx.grads * dloss), None, None, None, None
+        grads, ctx.grads = ctx.grads, None
+        if not ctx.prescaled:
+            grads.mul_(dloss)   # in place: the buffer is ours until it is delivered
+        return ctx.model._deliver_grad(grads), None, None, None, None
 
 
 class ViTSegmentationModel(nn.Module):
@@ -310,6 +313,19 @@ class ViTSegmentationModel(nn.Module):
     def _release_grad_buffer(self, grads: torch.Tensor) -> None:
         if getattr(self, "_grad_buf", None) is not None and grads.data_ptr() == self._grad_buf.data_ptr():
             self._grad_busy = False
+
+    def _deliver_grad(self, grads: torch.Tensor) -> None:
+        """Hands d loss / d arena to the parameter from inside an autograd backward and returns None for autograd (= no
+        gradient through the graph edge): with no gradient pending, the buffer vitseg_backward wrote BECOMES `arena.grad`
+        -- no copy; `_take_grad_buffer` will not hand it out again while it is installed -- otherwise it is added to the
+        pending one (gradient accumulation), after which the buffer is free again."""
+        with torch.no_grad():
+            if self.arena.grad is None:
+                self.arena.grad = grads
+            else:
+                self.arena.grad.add_(grads)
+        self._release_grad_buffer(grads)
+        return None
 
     def _backward(self, x: torch.Tensor, target: Optional[torch.Tensor] = None,
                   grad_logits: Optional[torch.Tensor] = None, drop=(0.0, 0), loss_scale: float = 1.0):
