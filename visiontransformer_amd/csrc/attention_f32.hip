@@ -65,8 +65,14 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
     // attention-probability dropout (modeling_vit.py:184): P is dropped AFTER normalisation, so the row sum l
     // keeps every term and only the P that multiplies V is masked / rescaled
     const unsigned dkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * (Np + 1) + q_local));
-    // ---- online-softmax state, initialised with the CLS key ----
+    // ---- softmax state, initialised with the CLS key ----
+    // No running maximum: every exponential of the row is taken against ONE reference m0 (the CLS score; it only moves on
+    // the guarded rare path below), carried as the MFMA C operand -m0, so the loop's vector work per score is exp2 + one
+    // add.  On this chip the fp32 matrix instruction and the vector ALU do not overlap (profiles/
+    // r03_simd_overlap_probe_fp32_mfma.txt): the max / subtract / rescale instructions of the classic online softmax
+    // (about 130 per 64-key tile and wave) were time added to the MFMAs, not hidden behind them.
     float m_run, l_run;
+    f32x16 negm;
     f32x16 o[2];
     {
         float part = 0.f;
@@ -77,6 +83,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
             for (int e = 0; e < 4; ++e) part = fmaf(qreg[4 * c + e], t[e], part);
         }
         m_run = part + __shfl_xor(part, 32, 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
         l_run = lh == 0 ? 1.f : 0.f;  // halves are summed at the end
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -98,14 +106,25 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
     // ---- K/V tile staging: thread owns 16-B chunk lc of keys lr + 16 i ----
     const int lc = tid & 15, lr = tid >> 4;
     f32x4 rk[4], rv[4];
+    // whole tiles: a scalar tile base + this thread's constant 32-bit byte offsets (no 64-bit address arithmetic in the
+    // loop -- on the fp32 path every vector instruction is time added to the MFMAs)
+    unsigned goff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) goff[i] = (unsigned)(((lr + 16 * i) * ld + 4 * lc) * 4);
     auto gload = [&](int kt) {
+        const char* tk = (const char*)(kbase + (row0 + (size_t)kt * KB) * ld);
+        const char* tv = (const char*)(vbase + (row0 + (size_t)kt * KB) * ld);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int key = kt * KB + lr + 16 * i;
-            if (RAGGED) key = min(key, Np - 1);  // duplicates are masked below
-            const size_t off = (row0 + key) * ld + 4 * lc;
-            rk[i] = *(const f32x4*)(kbase + off);
-            rv[i] = *(const f32x4*)(vbase + off);
+            if (RAGGED) {
+                const int key = min(kt * KB + lr + 16 * i, Np - 1);  // duplicates are masked below
+                const size_t off = (row0 + key) * ld + 4 * lc;
+                rk[i] = *(const f32x4*)(kbase + off);
+                rv[i] = *(const f32x4*)(vbase + off);
+            } else {
+                rk[i] = *(const f32x4*)(tk + goff[i]);
+                rv[i] = *(const f32x4*)(tv + goff[i]);
+            }
         }
     };
     auto swrite = [&](int buf) {
@@ -128,48 +147,71 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
         const float* Ks = lds[buf][0];
         const float* Vs = lds[buf][1];
 
-        // S^T[key][query] for 2 blocks of 32 keys
+        // S^T[key][query] - m0 for 2 blocks of 32 keys (the accumulators start at -m0)
         f32x16 st[2];
+        auto scores = [&](const f32x16& c0) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb) {
+                st[kb] = c0;
+                const int key = kb * 32 + li;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-            const int key = kb * 32 + li;
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 kf = *(const f32x4*)&Ks[key * HD + (((2 * c + lh) ^ (key & 15)) << 2)];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const f32x4 kf = *(const f32x4*)&Ks[key * HD + (((2 * c + lh) ^ (key & 15)) << 2)];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    st[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[4 * c + e], st[kb], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e)
+                        st[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[4 * c + e], st[kb], 0, 0, 0);
+                }
             }
-        }
-        if (RAGGED) {
+            if (RAGGED) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kt * KB + kb * 32 + kappa(r, lh) >= Np) st[kb][r] = -INFINITY;
-        }
-        // online softmax for this lane's query
-        float mx = st[0][0];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+                    for (int r = 0; r < 16; ++r)
+                        if (kt * KB + kb * 32 + kappa(r, lh) >= Np) st[kb][r] = -INFINITY;
+            }
+        };
+        scores(negm);
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(st[kb][r]);
                 st[kb][r] = pv;
                 psum += pv;
             }
-        l_run = l_run * alpha + psum;
+        // guard: a score more than ~100 log2 units above the reference (or a non-finite one).  Rare: the tile is redone
+        // against a new reference = the larger of the old one and this tile's maximum, the classic rescale of l and O.
+        if (__builtin_amdgcn_ballot_w64(!(psum <= 0x1p100f)) != 0ull) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            scores(zero);
+            float mx = st[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -m_new;
+            psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+                    st[kb][r] = pv;
+                    psum += pv;
+                }
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        l_run += psum;
         if (dr.thresh) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -178,11 +220,6 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
                     st[kb][r] = drop_keep(dkey, (unsigned)(kt * KB + kb * 32 + kappa(r, lh)), dr.thresh)
                                     ? st[kb][r] * dr.scale : 0.f;
         }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-
         // O^T[d][query] += V^T[d][key] . P^T[key][query]
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
