@@ -255,14 +255,30 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
                 }
                 pk[r >> 1] = pack2_bf16(d0, d1);
             }
+            // the 4 dQ MFMAs with their transposed K fragments (two ds_read_b64_tr_b16 each) read TWO MFMAs ahead: left alone,
+            // hipcc issues a fragment's reads and waits for them right in front of its MFMA (dQ 422 -> 401 us per layer)
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                bf16x8 fr[4];   // i = 2 s + dt
+                auto ldf = [&](int i) { fr[i] = tr_frag(Ks, kb * 32 + 16 * (i >> 1), i & 1, lane); };
+                ldf(0);
+                ldf(1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 dsf = __builtin_bit_cast(bf16x8, (uint4){pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]});
+                for (int i = 0; i < 4; ++i) {
+                    if (i + 2 < 4) ldf(i + 2);
+                    const int s = i >> 1, dt = i & 1;
+                    const bf16x8 dsf = __builtin_bit_cast(bf16x8, (uint4){pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]});
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], dsf, dq[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, kb * 32 + 16 * s, dt, lane), dsf, dq[dt],
-                                                                     0, 0, 0);
+                for (int i = 0; i < 2; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (MW) lm.load(mrow + (size_t)min(kt + 1, nkt - 1) * 32);   // next tile's lane masks (see TileMasks)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 have landed
@@ -478,6 +494,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                     }
                 }
             }
+            // (reading these fragments ahead of their MFMAs, as the dQ kernel does, needs 8 more registers than the 168 of three
+            // waves per SIMD leave: measured 597 -> 766 us per layer with the spills, so each fragment is read where it is used)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, (uint4){pp[4 * s], pp[4 * s + 1], pp[4 * s + 2], pp[4 * s + 3]});
