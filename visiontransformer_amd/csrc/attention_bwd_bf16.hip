@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
 
-    float rs = 0.f, rdl = 0.f;
+    float rs = 0.f, rdl = 0.f, raw_l = 0.f, raw_d = 0.f;
+    int raw_q = 0;
     unsigned rkey = 0;
     // mask words of this lane's KEY (both lane halves the same key): one word per 32-query group, bit = query.
     // Word position inside the key's 32-key block: 2 r + h with key = kappa(r, h).
@@ -389,36 +390,48 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&lds[0][0][0];
     // the tile's row constants and (MW) this key's mask words travel through registers as before: gload fetches them,
     // swrite publishes the row constants next to the tile
-    auto gload = [&](int qt, int buf) {
+    // gload_half(.., 0): the Q tile + the row constants / mask words; (.., 1): the dO tile.  In the loop the two halves are
+    // issued right behind the S / dP MFMAs of the two query blocks -- the wave would otherwise only wait for those MFMAs
+    // there, while at the top of the tile the ~300 cycles of DMA issue had nothing to hide behind.
+    auto gload_half = [&](int qt, int buf, int half) {
         const unsigned dst = lds_base + (unsigned)(buf * 2 * TT * HD * 2 + wv * 2048);
+        if (half == 1) {
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-            dma_piece(dst + pc * 1024, vq[pc], q_rsrc, (unsigned)(qt * TT * ld * 2));
-            dma_piece(dst + TT * HD * 2 + pc * 1024, vo[pc], o_rsrc, (unsigned)(qt * TT * D * 2));
+            for (int pc = 0; pc < 2; ++pc) dma_piece(dst + TT * HD * 2 + pc * 1024, vo[pc], o_rsrc, (unsigned)(qt * TT * D * 2));
+            return;
         }
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) dma_piece(dst + pc * 1024, vq[pc], q_rsrc, (unsigned)(qt * TT * ld * 2));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (MW) nw[i] = __builtin_amdgcn_raw_buffer_load_b32(mw_rsrc, mw_voff, (unsigned)((qt * 2 + i) * mnb * 32 * 4), 0);
         if (tid < TT) {
-            const int q = qt * TT + tid;
-            const bool ok = !RAGGED || q < Np;
-            // a query beyond the last patch gets p = exp2(c * -inf) = 0 and contributes nothing (its row constants read as
-            // zeros: out of the descriptors' range)
+            // (only REQUESTED here: the arithmetic on them waits in swrite, at the tile's end -- done here, wave 0 sat out
+            // the loads' latency at the start of every tile while waves 1-3 went ahead and then waited for it at the
+            // barrier: 350-450 of a tile's ~5 400 cycles, tools/probes/attn_bwd_trace.sh)
             const unsigned so = (unsigned)(qt * TT * 4);
-            const float l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, (unsigned)(tid * 4), so, 0));
-            const float dd = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dl_rsrc, (unsigned)(tid * 4), so, 0));
-            rs = ok ? -l * inv_c : -INFINITY;
-            rdl = ok ? -dd : 0.f;
-            // the query's dropout key, hashed ONCE per query here instead of once per (query, key) element below
-            if (DROP && !MW) rkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + q));
+            raw_l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, (unsigned)(tid * 4), so, 0));
+            raw_d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dl_rsrc, (unsigned)(tid * 4), so, 0));
+            raw_q = qt * TT + tid;
         }
     };
     auto swrite = [&](int buf) {
         if (tid < TT) {
+            const bool ok = !RAGGED || raw_q < Np;
+            // a query beyond the last patch gets p = exp2(c * -inf) = 0 and contributes nothing (its row constants read as
+            // zeros: out of the descriptors' range)
+            rs = ok ? -raw_l * inv_c : -INFINITY;
+            rdl = ok ? -raw_d : 0.f;
+            // the query's dropout key, hashed ONCE per query here instead of once per (query, key) element below
+            if (DROP && !MW) rkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + raw_q));
             stats[buf][0][tid] = rs;
             stats[buf][1][tid] = rdl;
             stats[buf][2][tid] = __uint_as_float(rkey);
         }
+    };
+    auto gload = [&](int qt, int buf) {
+        gload_half(qt, buf, 0);
+        gload_half(qt, buf, 1);
     };
     const int nqt = (Np + TT - 1) / TT;
     gload(0, 0);
@@ -428,7 +441,6 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
     for (int qt = 0; qt < nqt; ++qt) {
         const int buf = qt & 1;
         const unsigned cw[2] = {nw[0] >> (4 * lh), nw[1] >> (4 * lh)};   // bit 8 g4 + e = register 4 g4 + e of this lane half
-        gload(min(qt + 1, nqt - 1), buf ^ 1);
         const bf16_t* Qs = lds[buf][0];
         const bf16_t* Os = lds[buf][1];
 #pragma unroll
@@ -457,6 +469,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, oa),
                                                              __builtin_bit_cast(bf16x8, vf[s]), dp, 0, 0, 0);
             }
+            gload_half(min(qt + 1, nqt - 1), buf ^ 1, qb);   // next tile: half of its staging behind these 8 MFMAs
             unsigned pp[8], pd[8];  // P~ and dS fragments (B operands), query = register index
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
