@@ -103,46 +103,53 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
         }
     }
 
-    // ---- K/V tile staging: thread owns 16-B chunk lc of keys lr + 16 i ----
-    const int lc = tid & 15, lr = tid >> 4;
-    f32x4 rk[4], rv[4];
-    // whole tiles: a scalar tile base + this thread's constant 32-bit byte offsets (no 64-bit address arithmetic in the
-    // loop -- on the fp32 path every vector instruction is time added to the MFMAs)
-    unsigned goff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) goff[i] = (unsigned)(((lr + 16 * i) * ld + 4 * lc) * 4);
-    auto gload = [&](int kt) {
-        const char* tk = (const char*)(kbase + (row0 + (size_t)kt * KB) * ld);
-        const char* tv = (const char*)(vbase + (row0 + (size_t)kt * KB) * ld);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (RAGGED) {
-                const int key = min(kt * KB + lr + 16 * i, Np - 1);  // duplicates are masked below
-                const size_t off = (row0 + key) * ld + 4 * lc;
-                rk[i] = *(const f32x4*)(kbase + off);
-                rv[i] = *(const f32x4*)(vbase + off);
-            } else {
-                rk[i] = *(const f32x4*)(tk + goff[i]);
-                rv[i] = *(const f32x4*)(tv + goff[i]);
-            }
-        }
+    // ---- K/V tile staging by LDS-DMA (buffer_load_dwordx4 ... lds): a wave instruction moves 4 key rows x 256 B straight
+    // into the tile (lane l lands at + 16 l: row l >> 4, chunk position l & 15; K's XOR swizzle is applied to the per-lane
+    // SOURCE chunk); wave w fills keys [16 w, 16 w + 16) of K and of V: 8 instructions per tile.  No staging registers, no
+    // ds_write, no lgkmcnt wait in front of the tile barrier (the register-staged form spent ~4 % of the kernel there,
+    // tools/probes/attn_f32_where.sh); keys beyond Np are out of the descriptor's range and read as zeros (RAGGED masks
+    // them below).
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [](const void* base, long long bytes) {
+        const unsigned long long bb = (unsigned long long)base;
+        i32x4 r;
+        r[0] = (int)(unsigned)bb;
+        r[1] = (int)(unsigned)((bb >> 32) & 0xffffu);   // stride 0
+        r[2] = (int)(bytes < 0x7fffffffll ? bytes : 0x7fffffffll);
+        r[3] = 0x00020000;
+        return r;
     };
-    auto swrite = [&](int buf) {
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const i32x4 k_rsrc = make_rsrc(kbase + row0 * ld, ((long long)(Np - 1) * ld + HD) * 4);
+    const i32x4 v_rsrc = make_rsrc(vbase + row0 * ld, ((long long)(Np - 1) * ld + HD) * 4);
+    unsigned voffk[4], voffv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = 16 * wv + 4 * i + (lane >> 4);
+        voffk[i] = (unsigned)(key * ld * 4 + (((lane & 15) ^ (key & 15)) << 4));
+        voffv[i] = (unsigned)(key * ld * 4 + ((lane & 15) << 4));
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&lds[0][0][0];
+    auto stage = [&](int kt, int buf) {
+        const unsigned soff = (unsigned)(kt * KB * ld * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int key = lr + 16 * i;
-            *(f32x4*)&lds[buf][0][key * HD + ((lc ^ (key & 15)) << 2)] = rk[i];  // K: chunk ^ (key & 15)
-            *(f32x4*)&lds[buf][1][key * HD + (lc << 2)] = rv[i];                 // V: linear
+            const unsigned dk = lds_base + (unsigned)(((buf * 2 + 0) * KB * HD + (16 * wv + 4 * i) * HD) * 4);
+            const unsigned dv = lds_base + (unsigned)(((buf * 2 + 1) * KB * HD + (16 * wv + 4 * i) * HD) * 4);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dk), "v"(voffk[i]), "s"(k_rsrc), "s"(soff) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dv), "v"(voffv[i]), "s"(v_rsrc), "s"(soff) : "memory");
         }
     };
 
     const int nkt = (Np + KB - 1) / KB;
-    gload(0);
-    swrite(0);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        gload(min(kt + 1, nkt - 1));  // the last tile re-stages itself: keeps the body branch-free
+        stage(min(kt + 1, nkt - 1), buf ^ 1);  // the last tile re-stages itself: keeps the body branch-free
         __builtin_amdgcn_sched_barrier(0);  // pin the issue point of the prefetch
         const float* Ks = lds[buf][0];
         const float* Vs = lds[buf][1];
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
                 }
             }
 
-        swrite(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 have landed
         __syncthreads();
     }
 
