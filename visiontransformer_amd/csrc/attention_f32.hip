@@ -143,6 +143,70 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
         }
     };
 
+    // ---- the CLS QUERY of this (image, head) rides in the block of row tile 0 (it used to be a second kernel that streamed
+    // all K / V again: 36 us per layer at batch 32).  Thread = (16-byte chunk cq of the 64 channels, key subset cks): per
+    // key tile it scores its 4 keys against the CLS query on its 4 channels (completed across the 16 lanes of the subset),
+    // keeps an online softmax per subset and accumulates its chunk of P.V; the 16 subsets are merged at the end.  About
+    // 70 vector instructions per tile and wave, in one block out of eight.
+    const bool cls_blk = at.rt == 0;
+    const int cq = lane & 15, cks = tid >> 4;
+    f32x4 cq4 = {0.f, 0.f, 0.f, 0.f}, co = {0.f, 0.f, 0.f, 0.f};
+    float cm = -1e30f, cl = 0.f;
+    unsigned ckey = 0;
+    auto dot16 = [&](const f32x4& a, const f32x4& bb) {   // 4-channel partial, completed across the subset's 16 lanes
+        float t = a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2] + a[3] * bb[3];
+        // DPP inside the 16-lane row (vector-ALU operand modifiers: row_ror 8, row_ror 4, then the two quad swaps), not
+        // four trips through the LDS crossbar
+        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x128, 0xf, 0xf, true));
+        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x124, 0xf, 0xf, true));
+        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4e, 0xf, 0xf, true));
+        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xb1, 0xf, 0xf, true));
+        return t;
+    };
+    if (cls_blk) {
+        cq4 = *(const f32x4*)(qbase + cls_row * ld + 4 * cq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cq4[e] *= qscale;
+        ckey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * (Np + 1) + Np));
+        const float scc = dot16(cq4, *(const f32x4*)(kbase + cls_row * ld + 4 * cq));   // the CLS key: subset 0 starts from it
+        if (cks == 0) {
+            cm = scc;
+            cl = 1.f;
+            co = *(const f32x4*)(vbase + cls_row * ld + 4 * cq);
+            if (dr.thresh) {
+                const float kc = drop_keep(ckey, (unsigned)Np, dr.thresh) ? dr.scale : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) co[e] *= kc;
+            }
+        }
+    }
+    auto cls_tile = [&](int kt, const float* Ks, const float* Vs) {
+        float sc[4];
+        f32x4 v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = 4 * cks + u;
+            const f32x4 kf = *(const f32x4*)&Ks[key * HD + ((cq ^ (key & 15)) << 2)];
+            v4[u] = *(const f32x4*)&Vs[key * HD + (cq << 2)];
+            sc[u] = dot16(cq4, kf);
+            if (RAGGED && kt * KB + key >= Np) sc[u] = -INFINITY;
+        }
+        const float m_new = fmaxf(fmaxf(fmaxf(cm, sc[0]), fmaxf(sc[1], sc[2])), sc[3]);
+        const float alpha = __builtin_amdgcn_exp2f(cm - m_new);
+        cm = m_new;
+        cl *= alpha;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) co[e] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float pv = __builtin_amdgcn_exp2f(sc[u] - m_new);
+            cl += pv;
+            if (dr.thresh) pv = drop_keep(ckey, (unsigned)(kt * KB + 4 * cks + u), dr.thresh) ? pv * dr.scale : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) co[e] = fmaf(pv, v4[u][e], co[e]);
+        }
+    };
+
     const int nkt = (Np + KB - 1) / KB;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -153,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
         __builtin_amdgcn_sched_barrier(0);  // pin the issue point of the prefetch
         const float* Ks = lds[buf][0];
         const float* Vs = lds[buf][1];
+        if (cls_blk) cls_tile(kt, Ks, Vs);
 
         // S^T[key][query] - m0 for 2 blocks of 32 keys (the accumulators start at -m0)
         f32x16 st[2];
@@ -261,9 +326,35 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
                 *(f32x4*)(out + dt * 32 + 8 * g4 + 4 * lh) = t;
             }
     }
+    // ---- the CLS query: merge the 16 key subsets (the tile buffers are free: the loop ended with a barrier and no DMA
+    // is in flight) ----
+    if (cls_blk) {
+        float* red = &lds[0][0][0];   // [16][64] partial outputs, then 16 maxima, 16 sums
+        *(f32x4*)&red[cks * 64 + 4 * cq] = co;
+        if (cq == 0) {
+            red[1024 + cks] = cm;
+            red[1040 + cks] = cl;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float M = red[1024];
+#pragma unroll
+            for (int g = 1; g < 16; ++g) M = fmaxf(M, red[1024 + g]);
+            float L = 0.f, O = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float w = __builtin_amdgcn_exp2f(red[1024 + g] - M);
+                L = fmaf(red[1040 + g], w, L);
+                O = fmaf(red[g * 64 + tid], w, O);
+            }
+            ctx[cls_row * (size_t)D + head * HD + tid] = O / L;
+            if (lse && tid == 0) lse[((size_t)b * A + head) * (Np + 1) + Np] = M + __builtin_amdgcn_logf(L);
+        }
+    }
 }
 
-// The B*A CLS queries: one block per (head, image); plain VALU (1 x N x 64 per block).
+// The B*A CLS queries for the split-operand (x3) path, whose patch kernel does not carry them: one block per (head, image);
+// plain VALU (1 x N x 64 per block).
 __global__ __launch_bounds__(1024) void attn_cls_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                            float* __restrict__ lse, int B, int Np, int A,
                                                            DropArgs dr) {
@@ -374,6 +465,7 @@ int launch_attention_f32(const float* qkv, float* ctx, float* lse, int B, int Np
         hipLaunchKernelGGL(attn_f32_kernel<true>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr);
     }
     VITSEG_LAUNCH_CHECK("attn_f32");
+    if (!x3) return VITSEG_OK;   // the fp32 kernel carries the CLS queries itself (row tile 0 of every image and head)
     const size_t smem = (size_t)(((Np + 1 + 63) & ~63) + 64 * 64) * sizeof(float);
     VITSEG_CHECK_ARG(smem <= 64 * 1024, VITSEG_ESHAPE, "attention_f32: sequence too long for the CLS kernel");
     hipLaunchKernelGGL(attn_cls_f32_kernel, dim3(A, B), dim3(1024), smem, s, qkv, ctx, lse, B, Np, A, dr);
