@@ -177,7 +177,6 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (MW) lm.wait();
-        stage(min(kt + 1, nkt - 1), buf ^ 1);  // the last tile re-stages itself: keeps the body branch-free
         const bf16_t* Ks = lds[buf][0];
         const bf16_t* Vs = lds[buf][1];
 
@@ -203,6 +202,9 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restr
             }
         };
         scores();
+        // the next tile's DMA is issued HERE, behind the 8 QK^T MFMAs the wave would otherwise only wait for (at the top of
+        // the tile the ~250 cycles of issue had nothing to hide behind); the last tile re-stages itself: branch-free body
+        stage(min(kt + 1, nkt - 1), buf ^ 1);
         float nmc = -m_run * c;   // p = exp2(c s - c m): the running maximum enters through the fma's addend
         float psum;
         unsigned pk[2][8];  // P^T fragments: pk[kb][4 s + w] = registers 8 s + 2 w, 8 s + 2 w + 1

@@ -205,7 +205,6 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (MW) lm.wait();
-        stage(min(kt + 1, nkt - 1), buf ^ 1);
         const bf16_t* Ks = lds[buf][0];
         const bf16_t* Vs = lds[buf][1];
         // one 32-key block at a time (S, dP -> dS -> dQ^T): 32 score registers live instead of 64, which is what lets three
@@ -228,6 +227,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
                                                              __builtin_bit_cast(bf16x8, dof[s]), dp, 0, 0, 0);
             }
+            if (kb == 0) stage(min(kt + 1, nkt - 1), buf ^ 1);   // next tile's DMA behind these 8 MFMAs (see the dK/dV kernel)
             unsigned pk[8];  // dS^T fragments: words 4 s + w = registers 8 s + 2 w, + 1
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
