@@ -37,10 +37,10 @@ from visiontransformer_amd.model import ViTSegmentationModel  # noqa: E402
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f32x3": 2500.0 / 3}  # x3: 3 fp16 MFMAs per product  # dense MFMA peaks, MI355X_MICROARCH.md
 KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
     # fp32 linears with >= 128 tiles of 256x128: the persistent kernel gemm_f32p_kernel<EPI, DROP, AUX, INL> (csrc/gemm_f32p.hip)
-    "f32": {"gemm_bias": "gemm_f32p_kernel<0, false, false, true>", "gemm_gelu": "gemm_f32p_kernel<1, false, false, false>",
+    "f32": {"gemm_bias": "gemm_f32p_kernel<0, false, false, true>", "gemm_gelu": "gemm_f32p_kernel<1, false, false, true>",
             "gemm_resadd": "gemm_f32p_kernel<2, false, false, true>", "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
             "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 0>",
-            "attention": "attn_f32_kernel<false> + attn_cls_f32_kernel"},
+            "attention": "attn_f32_kernel<false>"},   # (carries the CLS query too)
     # 16-bit operands: the 8-phase persistent kernel gemm_p8_kernel<T, OutT, EPI, TT> (csrc/gemm_p8.hip) whenever
     # M >= 2048, N % 256 == 0, K % 128 == 0 -- every encoder linear at the bench batch sizes
     "bf16": {"gemm_bias": "gemm_p8_kernel<unsigned short, unsigned short, 0, 0>",
@@ -70,7 +70,7 @@ KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
                                      "attn_bwd_cls_bf16_kernel<true> + attn_delta_bf16_kernel"},
     "train_f32": {"train_gemm_fwd": "gemm_kernel<float, float, 0, {0,1,2}, ...>", "train_dgrad": "gemm_kernel<float, float, ...> (W T-form)",
                   "train_wgrad": "gemm_kernel<float, float, ...> (both T-form, split-K)",
-                  "train_attn_fwd": "attn_f32_kernel<true> + attn_cls_f32_kernel",
+                  "train_attn_fwd": "attn_f32_kernel<true>",
                   "train_attn_bwd": "attn_bwd_dq_f32_kernel + attn_bwd_dkv_f32_kernel"},
 }
 
