@@ -43,7 +43,8 @@ KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
             "attention": "attn_f32_kernel<false>"},   # (carries the CLS query too)
     # 16-bit operands: the 8-phase persistent kernel gemm_p8_kernel<T, OutT, EPI, TT> (csrc/gemm_p8.hip) whenever
     # M >= 2048, N % 256 == 0, K % 128 == 0 -- every encoder linear at the bench batch sizes
-    "bf16": {"gemm_bias": "gemm_p8_kernel<unsigned short, unsigned short, 0, 0>",
+    # (the QKV projection -- bias epilogue, K <= 1024 -- runs on gemm_h16p_kernel<T>, csrc/gemm_h16p.hip)
+    "bf16": {"gemm_bias": "gemm_h16p_kernel<unsigned short>",
              "gemm_gelu": "gemm_p8_kernel<unsigned short, unsigned short, 1, 0>",
              "gemm_resadd": "gemm_p8_kernel<unsigned short, float, 2, 0>",
              "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
@@ -54,7 +55,7 @@ KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
               "gemm_conv3": "gemm_kernel<float, float, 2, 3, 0, 0, 2>",
               "attention": "attn_x3_kernel<false> + attn_cls_f32_kernel"},
     # rocprofv3's demangler does not know _Float16 (DF16_): the IEEE-half instantiations appear mangled in its CSVs
-    "f16": {"gemm_bias": "_ZN6vitseg14gemm_p8_kernelIDF16_DF16_Li0ELi0EEEvNS_8GemmArgsE",
+    "f16": {"gemm_bias": "_ZN6vitseg12_GLOBAL__N_116gemm_h16p_kernelIDF16_EEvNS_8GemmArgsE",
             "gemm_gelu": "_ZN6vitseg14gemm_p8_kernelIDF16_DF16_Li1ELi0EEEvNS_8GemmArgsE",
             "gemm_resadd": "_ZN6vitseg14gemm_p8_kernelIDF16_fLi2ELi0EEEvNS_8GemmArgsE",
             "gemm_patch": "gemm_kernel<float, float, 1, 4, 0, 0, 0>",
@@ -62,13 +63,13 @@ KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
             "attention": "_ZN6vitseg12_GLOBAL__N_116attn_bf16_kernelILb0ELb0ELb0EDF16_EEvPKtPtPfiiiNS_8DropArgsEPKj + "
                          "_ZN6vitseg12_GLOBAL__N_120attn_cls_bf16_kernelIDF16_EEvPKtPtPfiiiNS_8DropArgsE"},
     # training step (--mode train): kernel groups bracketed by the VITSEG_K_TRAIN_* scopes (csrc/vitseg_train.hip)
-    "train_bf16": {"train_gemm_fwd": "gemm_p8_kernel<unsigned short, *, {0,1,2}, 0> (the four forward linears)",
-                   "train_dgrad": "gemm_p8_kernel<unsigned short, *, {0,5}, 0> + transpose_bf16_kernel (activation gradients)",
+    "train_bf16": {"train_gemm_fwd": "gemm_h16p_kernel<unsigned short> (QKV) + gemm_p8_kernel<unsigned short, *, {1,2}, 0> (the four forward linears)",
+                   "train_dgrad": "gemm_p8_kernel<unsigned short, *, {0,5}, 0> + gemm_h16p_kernel<unsigned short> (o_proj) + transpose_bf16_kernel (activation gradients)",
                    "train_wgrad": "gemm_p8_kernel<unsigned short, float, 0, 1> + splitk_reduce_kernel (weight gradients)",
                    "train_attn_fwd": "attn_dropmask_kernel + attn_bf16_kernel<true, false, true, unsigned short> + attn_cls_bf16_kernel<unsigned short>",
                    "train_attn_bwd": "attn_bwd_dkv_bf16_kernel<true, false, true> + attn_bwd_dq_bf16_kernel<true, false, true> + "
                                      "attn_bwd_cls_bf16_kernel<true> + attn_delta_bf16_kernel"},
-    "train_f32": {"train_gemm_fwd": "gemm_kernel<float, float, 0, {0,1,2}, ...>", "train_dgrad": "gemm_kernel<float, float, ...> (W T-form)",
+    "train_f32": {"train_gemm_fwd": "gemm_f32p_kernel<{0,1,2}, ...> (the four forward linears)", "train_dgrad": "gemm_kernel<float, float, ...> (W T-form)",
                   "train_wgrad": "gemm_kernel<float, float, ...> (both T-form, split-K)",
                   "train_attn_fwd": "attn_f32_kernel<true>",
                   "train_attn_bwd": "attn_bwd_dq_f32_kernel + attn_bwd_dkv_f32_kernel"},
