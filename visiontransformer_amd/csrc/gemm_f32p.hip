@@ -494,18 +494,6 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
 #undef F32P_DMA
 }
 
-int f32p_num_cus() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    static int ncu[64] = {};
-    if (!ncu[dev]) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return ncu[dev];
-}
-
 template <int EPI, bool DROP, bool AUX, bool INL>
 int launch_f32p_one_i(const GemmArgs& a, hipStream_t s) {
     int dev = 0;
@@ -518,7 +506,7 @@ int launch_f32p_one_i(const GemmArgs& a, hipStream_t s) {
         attr_set[dev] = true;
     }
     const int tiles = ((a.M + FM - 1) / FM) * (a.N / FN);
-    const int ncu = f32p_num_cus();
+    const int ncu = device_num_cus();
     hipLaunchKernelGGL((gemm_f32p_kernel<EPI, DROP, AUX, INL>), dim3(tiles < ncu ? tiles : ncu), dim3(256), F32P_LDS, s, a);
     VITSEG_LAUNCH_CHECK("gemm_f32p");
     return VITSEG_OK;

@@ -475,18 +475,6 @@ __global__ __launch_bounds__(256) void gemm_h16p_kernel(const GemmArgs p) {
 #undef Q_DMA
 }
 
-int h16p_num_cus() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    static int ncu[64] = {};
-    if (!ncu[dev]) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return ncu[dev];
-}
-
 template <typename T>
 int launch_h16p_t(const GemmArgs& a, hipStream_t s) {
     int dev = 0;
@@ -498,7 +486,7 @@ int launch_h16p_t(const GemmArgs& a, hipStream_t s) {
         attr_set[dev] = true;
     }
     const int tiles = ((a.M + QT - 1) / QT) * (a.N / QT);
-    const int ncu = h16p_num_cus();
+    const int ncu = device_num_cus();
     hipLaunchKernelGGL((gemm_h16p_kernel<T>), dim3(tiles < ncu ? tiles : ncu), dim3(256), Q_LDS, s, a);
     VITSEG_LAUNCH_CHECK("gemm_h16p");
     return VITSEG_OK;

@@ -517,7 +517,7 @@ bool gemm_p8_applies(const GemmArgs& a, int epi) {
            (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESADD || epi == EPI_DGELU);
 }
 
-static int p8_num_cus() {   // per device: a process may drive several
+int device_num_cus() {   // per device: a process may drive several
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
     static int ncu[64] = {};
@@ -531,7 +531,7 @@ static int p8_num_cus() {   // per device: a process may drive several
 
 // rounds of the persistent grid an NT launch with M rows takes (one 256 x 256 tile per CU and round)
 int gemm_p8_rounds(int M, int N) {
-    const int ncu = p8_num_cus();
+    const int ncu = device_num_cus();
     return (((M + PT - 1) / PT) * (N / PT) + ncu - 1) / ncu;
 }
 
@@ -545,7 +545,7 @@ static int launch_p8_one(GemmArgs a, int items, hipStream_t s) {
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_p8)");
         attr_set[dev] = true;
     }
-    const int ncu = p8_num_cus();
+    const int ncu = device_num_cus();
     const int grid = items < ncu ? items : ncu;
     hipLaunchKernelGGL((gemm_p8_kernel<T, OutT, EPI, TT>), dim3(grid), dim3(512), P8_LDS, s, a);
     VITSEG_LAUNCH_CHECK("gemm_p8");
@@ -581,7 +581,7 @@ bool wgrad_p8_applies(const GemmArgs& a) {
 }
 int wgrad_p8_splits(int M, int N, int K) {
     const int tiles = (M / PT) * (N / PT);
-    int splits = p8_num_cus() / tiles;
+    int splits = device_num_cus() / tiles;
     const int ksteps = (K + 63) / 64;
     if (splits > ksteps / 8) splits = ksteps / 8;   // >= 8 K steps per slice
     return splits < 1 ? 1 : splits;

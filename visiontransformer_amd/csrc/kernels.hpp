@@ -78,6 +78,8 @@ size_t wgrad_bf16_scratch_floats(int M, int N, int K);
 int launch_gemm_bf16(const GemmArgs& a, int amode, int epi, hipStream_t s, bool f16 = false);
 // persistent 8-phase 256x256 kernel for the large plain linear layers (gemm_p8.hip); `applies` = shape / alignment test
 int gemm_p8_rounds(int M, int N);
+// compute units of the current device (cached per device; 256 when the query fails): grid size of the persistent kernels
+int device_num_cus();
 bool gemm_p8_applies(const GemmArgs& a, int epi);
 int launch_gemm_p8(const GemmArgs& a, int epi, hipStream_t s, bool f16);
 // 16-bit persistent kernel for the bias epilogue with a short reduction (gemm_h16p.hip): one wave per SIMD, 128 x 128 per
