@@ -90,10 +90,10 @@ def algorithmic_bytes(precision, kind, cfg, batch):
 
 def pmc_traffic(precision, kernel_label, batch):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_pmc.sh bench_<prec> ... ->
-    tools/summarize_traffic.py -> profiles/r03_traffic_<prec>.json): counters cannot be read from inside this process,
+    tools/summarize_traffic.py -> profiles/rNN_traffic_<prec>.json, the newest round): counters cannot be read from inside this process,
     so the figure is the one rocprofv3 measured on this same command (batch 32).  None when no pass covers the run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r03_traffic_{precision}.json")
-    if batch != 32 or not os.path.exists(path):
+    path = traffic_profile(precision)
+    if batch != 32 or path is None:
         return None
     kernels = json.load(open(path))["kernels"]
     tot = n = 0.0
@@ -104,6 +104,13 @@ def pmc_traffic(precision, kernel_label, batch):
         tot += k["hbm_bytes_per_launch"] * k["launches_sampled"]
         n += k["launches_sampled"]
     return round(tot / n) if n else None
+
+
+def traffic_profile(precision):
+    """Newest committed profiles/rNN_traffic_<precision>.json (None if there is none)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_traffic_{precision}.json")))
+    return found[-1] if found else None
 
 
 def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.0):
@@ -145,21 +152,16 @@ def parity_vs(gpu_logits, gpu_mask, logits, mask):
             "images_checked": n}
 
 
-def bench_tiled(args, rank, world, dev, barrier):
-    """BASELINE configs[4]: ViT-L/16 seg inference on 1024x1024 inputs, fp16 operands by default; `--batch` 1024^2 images
-    per GPU (16 = the config's 128 over 8 GPUs).  Mask-only output, so the decoder tail writes 1 B/pixel.
-    l16_1024_tiled: four 512x512 tiles through an image_size=512 model (build-defined tiling, SURVEY 8d; N = 1025).
-    l16_1024_native: the image as ONE sequence of N = 4097 tokens through an image_size=1024 model (SURVEY 8d's
-    alternative: 3 738 GF per image, attention 44 % of it)."""
+def run_tiled(precision, native, B, rank, dev, steps, warmup, barrier, procedural_weights=True):
+    """ViT-L/16 on `B` 1024x1024 images per step, mask-only output.  Returns (cfg, seconds, profile, last mask)."""
     from visiontransformer_amd.config import vit_large16
-    native = args.workload == "l16_1024_native"
     S = 1024 if native else 512
     cfg = vit_large16(num_classes=2, image_size=S)
-    B = args.batch
     model = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
                                  cfg.num_attention_heads, image_size=S,
-                                 precision={"f32": "fp32", "bf16": "bf16", "f16": "fp16"}[args.precision], device=dev).eval()
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=1).items()})
+                                 precision={"f32": "fp32", "bf16": "bf16", "f16": "fp16"}[precision], device=dev).eval()
+    if procedural_weights:   # (else: the constructor's random init, reference initialisers, torch generator seed 0)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=1).items()})
     if native:
         x = torch.from_numpy(synth.make_images(cfg, B, seed=0, first_image=rank * B)).to(dev)
         run = model.predict_mask
@@ -169,20 +171,39 @@ def bench_tiled(args, rank, world, dev, barrier):
         del tiles
         run = model.predict_mask_tiled
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             mask = run(x)
         torch.cuda.synchronize()
         barrier()
         _lib.profile_enable(True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             mask = run(x)
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
+    return cfg, elapsed, prof, mask
+
+
+def hbm_rooflines(prof, kinds):
+    return {k: {"achieved_GBps": round(prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e9, 1), "peak_GBps": 8000.0,
+                "frac": round(prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 8e12, 4),
+                "bytes_per_launch": prof[k]["work"] / max(prof[k]["launches"], 1)}
+            for k in kinds if prof[k]["ms"] > 0}
+
+
+def bench_tiled(args, rank, world, dev, barrier):
+    """BASELINE configs[4]: ViT-L/16 seg inference on 1024x1024 inputs, fp16 operands by default; `--batch` 1024^2 images
+    per GPU (16 = the config's 128 over 8 GPUs).  Mask-only output, so the decoder tail writes 1 B/pixel.
+    l16_1024_tiled: four 512x512 tiles through an image_size=512 model (build-defined tiling, SURVEY 8d; N = 1025).
+    l16_1024_native: the image as ONE sequence of N = 4097 tokens through an image_size=1024 model (SURVEY 8d's
+    alternative: 3 738 GF per image, attention 44 % of it)."""
+    native = args.workload == "l16_1024_native"
+    B = args.batch
+    cfg, elapsed, prof, mask = run_tiled(args.precision, native, B, rank, dev, args.steps, args.warmup, barrier)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -218,12 +239,29 @@ def bench_tiled(args, rank, world, dev, barrier):
                             "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if not k.startswith("train_")},
             # the HBM-bandwidth-bound decoder head: low-res logits -> bilinear -> sigmoid/argmax -> 1 B/pixel
-            "roofline_hbm": {k: {"achieved_GBps": round(prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e9, 1),
-                                 "peak_GBps": 8000.0,
-                                 "frac": round(prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 8e12, 4),
-                                 "bytes_per_launch": prof[k]["work"] / max(prof[k]["launches"], 1)}
-                             for k in ("layernorm", "head1x1", "upsample") if prof[k]["ms"] > 0}}), flush=True)
+            "roofline_hbm": hbm_rooflines(prof, ("layernorm", "head1x1", "upsample"))}), flush=True)
     barrier()
+
+
+def side_l16_tiled_f16(dev, steps=5):
+    """BASELINE configs[4] at its per-GPU share inside the default line (rank 0, N = 1, outside the timed region):
+    ViT-L/16, 16 images of 1024x1024 as 64 tiles of 512x512, fp16, uint8 mask output.  Random-init weights from the
+    constructor (a throughput figure; the full-depth parity of this model is tests/test_gpu_forward.py)."""
+    B = 16
+    cfg, elapsed, prof, mask = run_tiled("f16", False, B, 0, dev, steps, 2, lambda: None, procedural_weights=False)
+    peak = PEAK_TFLOPS["f16"]
+    flops_img = 4.0 * cfg.forward_flops_per_image()
+    value = B * steps / elapsed
+    out = {"workload": "ViT-L/16 seg inference, 16 x 1024x1024 per GPU tiled 4 x 512x512, fp16, uint8 mask output "
+                       "(BASELINE.json configs[4], one GPU's share of the batch of 128)",
+           "images_per_s_per_gpu": round(value, 1), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
+           "whole_model_frac_of_f16_peak": round(value * flops_img / 1e12 / peak, 4),
+           "kernel_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items()
+                                  if not k.startswith("train_") and v["ms"] > 0},
+           "roofline_hbm": hbm_rooflines(prof, ("layernorm", "head1x1", "upsample"))}
+    del mask
+    torch.cuda.empty_cache()
+    return out
 
 
 def bench_aux(args, rank, world, dev, barrier):
@@ -314,13 +352,13 @@ def bench_aux(args, rank, world, dev, barrier):
     barrier()
 
 
-def bench_train(args, cfg, model, x, rank, world, dev, barrier):
-    """One step = LightningViTModel.training_step + backward + (N>1: RCCL all-reduce of the flat gradient
-    arena) + Adam(lr=1e-5): BASELINE configs[2]/[3] (--precision bf16 = mixed precision, --batch 64)."""
+def run_train_steps(model, x, y, world, steps, warmup, prof_steps, barrier):
+    """`warmup` untimed + `steps` timed training steps (LightningViTModel.training_step + backward + (N>1: RCCL all-reduce of
+    the flat gradient arena) + Adam(lr=1e-5)), then `prof_steps` further steps with hipEvents on the launch stream around
+    the GEMM / attention launches (outside the timed region, so the event records do not perturb the timing).
+    Returns (seconds of the timed steps on this rank, kernel-group profile, last loss)."""
     from visiontransformer_amd.dist import sync_grads
     from visiontransformer_amd.optim import FusedAdam
-    B = args.batch
-    y = torch.from_numpy(synth.make_targets(cfg, B, seed=0, first_image=rank * B, size=cfg.image_size)).to(dev)
     model.train()
     opt = FusedAdam(model.parameters(), lr=1e-5)
 
@@ -332,25 +370,39 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
         opt.step(grad_scale=1.0 / world)
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    # per-kernel-group device time: hipEvents on the launch stream around the GEMM / attention launches of PROF_STEPS
-    # further steps of the same loop (outside the timed region, so the event records do not perturb `value`)
-    PROF_STEPS = 3
     _lib.profile_enable(True)
-    for _ in range(PROF_STEPS):
+    for _ in range(prof_steps):
         step()
     torch.cuda.synchronize()
     prof = {k: v for k, v in _lib.profile_collect().items() if k.startswith("train_")}
     _lib.profile_enable(False)
+    return elapsed, prof, loss
+
+
+def kernel_groups(prof, prof_steps, peak):
+    return {k: {"ms_per_step": round(v["ms"] / prof_steps, 3),
+                "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None,
+                "frac": round(v["work"] / (v["ms"] * 1e-3) / 1e12 / peak, 4) if v["ms"] > 0 else None}
+            for k, v in prof.items()}
+
+
+def bench_train(args, cfg, model, x, rank, world, dev, barrier):
+    """One step = LightningViTModel.training_step + backward + (N>1: RCCL all-reduce of the flat gradient
+    arena) + Adam(lr=1e-5): BASELINE configs[2]/[3] (--precision bf16 = mixed precision, --batch 64)."""
+    B = args.batch
+    y = torch.from_numpy(synth.make_targets(cfg, B, seed=0, first_image=rank * B, size=cfg.image_size)).to(dev)
+    PROF_STEPS = 3
+    elapsed, prof, loss = run_train_steps(model, x, y, world, args.steps, args.warmup, PROF_STEPS, barrier)
     barrier()
     if world > 1:
         import torch.distributed as dist
@@ -376,20 +428,42 @@ def bench_train(args, cfg, model, x, rank, world, dev, barrier):
                        "parallelism": f"data-parallel x{world}, bucketed gradient all-reduce ({collective_name(world)}) "
                                       f"overlapped with the backward"},
             # dominant kernel group of the step (largest summed device time): algorithmic FLOPs / hipEvent time on the
-            # launch stream; per-kernel times of the same command: profiles/r03_bench_train_*_kernel_stats.csv
+            # launch stream; per-kernel times of the same command: profiles/rNN_bench_train_*_kernel_stats.csv
             "roofline": {"bound": "mfma", "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(dom_tflops / peak, 4), "traffic": None, "kernel": names.get(dom, dom),
                          "launches": d["launches"], "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                          "flops_per_launch": d["work"] / max(d["launches"], 1)},
-            "kernel_groups": {k: {"ms_per_step": round(v["ms"] / PROF_STEPS, 3),
-                                  "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None,
-                                  "frac": round(v["work"] / (v["ms"] * 1e-3) / 1e12 / peak, 4) if v["ms"] > 0 else None}
-                              for k, v in prof.items()},
+            "kernel_groups": kernel_groups(prof, PROF_STEPS, peak),
             "whole_model": {"flops_per_image": flops_img,
                             "achieved_tflops_per_gpu": round(value / world * flops_img / 1e12, 2),
                             "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},
             "final_loss": float(loss.detach())}), flush=True)
     barrier()
+
+
+def side_train_bf16(cfg, sd_np, x32, dev, steps=5):
+    """BASELINE configs[2] inside the default line (rank 0, N = 1, outside the timed region): ViT-B/16 training step,
+    batch 64 x 512x512, bf16 operands / fp32 master weights + Adam, the reference's dropout 0.1."""
+    B = 64
+    model = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+                                 cfg.num_attention_heads, image_size=cfg.image_size, precision="bf16", dropout=0.1, device=dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    n0 = x32.shape[0]
+    x = torch.cat([x32, torch.from_numpy(synth.make_images(cfg, B - n0, seed=0, first_image=n0)).to(dev)]) if n0 < B else x32[:B]
+    y = torch.from_numpy(synth.make_targets(cfg, B, seed=0, first_image=0, size=cfg.image_size)).to(dev)
+    PROF_STEPS = 2
+    elapsed, prof, loss = run_train_steps(model, x, y, 1, steps, 2, PROF_STEPS, lambda: None)
+    peak = PEAK_TFLOPS["bf16"]
+    flops_img = 3.0 * cfg.forward_flops_per_image()
+    value = B * steps / elapsed
+    out = {"workload": "ViT-B/16 seg TRAINING step (forward + CE + backward + Adam), batch 64 x 512x512, bf16 operands / "
+                       "fp32 master + Adam, dropout 0.1 (BASELINE.json configs[2])",
+           "images_per_s_per_gpu": round(value, 1), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
+           "whole_step_frac_of_bf16_peak": round(value * flops_img / 1e12 / peak, 4),
+           "kernel_groups": kernel_groups(prof, PROF_STEPS, peak), "final_loss": float(loss.detach())}
+    del model, x, y
+    torch.cuda.empty_cache()
+    return out
 
 
 def collective_name(world):
@@ -451,6 +525,9 @@ def main():
                     help="b16_512 = BASELINE configs[1] (default, the headline metric); l16_1024_tiled = configs[4]; "
                          "l16_1024_native = the same images as one 4097-token sequence each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the configs[2] / configs[4] side runs the default fp32 line appends (train_bf16_path, "
+                         "l16_1024_tiled_f16_path)")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode: dropout probability (reference 0.1)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "prep", "eval"],
                     help="train: one step = forward + CE + backward + gradient all-reduce + Adam (fp32)")
@@ -551,6 +628,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          "traffic": pmc_traffic(args.precision, KERNEL_NAMES[args.precision].get(dom, dom), B),
+                         "traffic_source": (f"profiles/{os.path.basename(traffic_profile(args.precision))} (committed rocprofv3 "
+                                            f"--pmc pass of this command, not measured by this run)"
+                                            if traffic_profile(args.precision) and B == 32 else None),
                          "traffic_note": "L2-miss bytes/launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc passes in "
                                          "profiles/); operand re-reads are served by the 256 MB Infinity Cache",
                          "algorithmic_bytes_per_launch": algorithmic_bytes(args.precision, dom, cfg, B),
@@ -562,11 +642,7 @@ def main():
                             "frac_of_peak": round(value / world * flops_img / 1e12 / peak, 4)},
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if not k.startswith("train_")},
             # the HBM-bound pieces against the 8 TB/s roof (algorithmic bytes / hipEvent time, same timed region)
-            "roofline_hbm": {k: {"achieved_GBps": round(prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e9, 1),
-                                 "peak_GBps": 8000.0,
-                                 "frac": round(prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 8e12, 4),
-                                 "bytes_per_launch": prof[k]["work"] / max(prof[k]["launches"], 1)}
-                             for k in ("layernorm", "upsample") if prof[k]["ms"] > 0},
+            "roofline_hbm": hbm_rooflines(prof, ("layernorm", "upsample")),
         }
         extras = not args.no_cpu_baseline and world == 1   # CPU baseline / side paths: N = 1 only (spec), rank 0
         if args.precision == "f32" and extras:
@@ -599,6 +675,16 @@ def main():
             out["parity"] = parity
             if args.precision == "f32":   # the split-operand path against the same oracle run
                 out["f32x3_path"]["parity_vs_oracle"] = parity_vs(lg_x3, mk_x3, *oracle_out)
+                lg_x3 = mk_x3 = lg2 = mk2 = None
+        if extras and args.precision == "f32" and B == 32 and args.classes == 2 and not args.no_side_configs:
+            # BASELINE configs[2] and configs[4] at one GPU, a few steps each (their own models; the fp32 model and its
+            # workspace are released first).  Outside the timed region: `value` is the fp32 inference step above.
+            del model
+            logits = mask = None
+            torch.cuda.empty_cache()
+            out["train_bf16_path"] = side_train_bf16(cfg, sd_np, x, dev)
+            x = None
+            out["l16_1024_tiled_f16_path"] = side_l16_tiled_f16(dev)
         print(json.dumps(out), flush=True)
     barrier()
     if world > 1:

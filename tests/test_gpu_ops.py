@@ -105,9 +105,8 @@ def test_linear_f32_persistent_kernel(M, N, K, epi, extra, monkeypatch):
         return C, aux
 
     C, aux = run()
-    monkeypatch.setenv("VITSEG_NO_F32P", "1")
-    C_old, aux_old = run()
-    monkeypatch.delenv("VITSEG_NO_F32P")
+    with _lib.option("no_f32p", 1):
+        C_old, aux_old = run()
     err = (C.cpu().double() - ref).abs().max().item()
     bound = 4e-7 * (A.abs().double() @ W.abs().double().T).max().item() * (1.2 if p else 1.0) + 1e-6
     assert err < bound, (err, bound)
@@ -331,11 +330,13 @@ def _drop_rows_np(M, N, p, seed, stream):
     (16400, 768, 768, 2, "drop"),        # 128x128, residual + dropout (o_proj forward at training batch)
 ])
 @pytest.mark.parametrize("fmt", ["bf16", "fp16"])
-def test_linear_h16_tile_variants(M, N, K, epi, extra, fmt, monkeypatch):
+def test_linear_h16_tile_variants(M, N, K, epi, extra, fmt, request):
     if fmt == "fp16" and (epi == 5 or "aux" in extra or "drop" in extra):
         pytest.skip("training epilogues exist for bf16 only (fp16 is an inference format)")
     if "thin" in extra:   # a ragged row tile that fits the persistent kernel's last round would ride along instead (gemm.hip)
-        monkeypatch.setenv("VITSEG_NO_RAGGED_P8", "1")
+        old = _lib.get_option("no_ragged_p8")
+        request.addfinalizer(lambda: _lib.set_option("no_ragged_p8", old))
+        _lib.set_option("no_ragged_p8", 1)
     dt, ulp, _, _ = FMT[fmt]
     A, W = _rand(M, K, seed=M).to(dt).float(), _rand(N, K, seed=N + 1, scale=0.05).to(dt).float()
     bias = _rand(N, seed=7, scale=0.1)

@@ -96,3 +96,130 @@ def test_no_wide_buffer_store_with_scalar_offset(src, flags, tmp_path):
     bad = [l.strip() for l in _asm(src, flags, tmp_path).splitlines()
            if re.match(r"\s*buffer_store_dwordx[34]\b", l) and re.search(r",\s*s\d+\s+offen", l.split(";")[0])]
     assert not bad, bad[:4]
+
+
+def _vgprs(text):
+    """VGPR numbers an operand string mentions (v7, v[4:7]; not a[..] / s[..])."""
+    regs = set()
+    for a, b in re.findall(r"(?<![\w\]])v\[(\d+):(\d+)\]", text):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(n) for n in re.findall(r"(?<![\w\]])v(\d+)\b", text))
+    return regs
+
+
+_VMEM = re.compile(r"^(buffer|global|flat|scratch)_")
+
+
+def _hand_load_violations(text):
+    """For every global/buffer load with a VGPR destination issued from INLINE ASM (hipcc neither counts it nor protects its
+    destination): walk every control-flow path from the load to the first `s_waitcnt vmcnt(N)` that covers it (vector-memory
+    instructions retire in order and vmcnt(N) leaves at most the N youngest outstanding, so the load has landed once N <= the
+    number issued after it) and report any instruction on the way that reads, writes or copies the destination registers.  Returns (number of hand-issued loads checked, list of violations)."""
+    lines, in_asm = [], []
+    asm = False
+    for raw in text.splitlines():
+        t = raw.split(";;#")[0] if ";;#" not in raw else raw.strip()
+        if ";;#ASMSTART" in raw:
+            asm = True
+            continue
+        if ";;#ASMEND" in raw:
+            asm = False
+            continue
+        t = raw.split(";")[0].strip()
+        if not t or (t.startswith(".") and not t.endswith(":")):
+            continue
+        lines.append(t)
+        in_asm.append(asm)
+    label_at = {t[:-1]: i for i, t in enumerate(lines) if t.endswith(":")}
+    checked, bad = 0, []
+    for i, t in enumerate(lines):
+        op, _, rest = t.partition(" ")
+        if not (in_asm[i] and re.match(r"(global|buffer)_load_dword", op)) or " lds" in " " + rest:
+            continue
+        dest = _vgprs(rest.split(",")[0])
+        if not dest:
+            continue
+        checked += 1
+        seen = {}
+        stack = [(i + 1, 0)]
+        while stack:
+            j, out = stack.pop()
+            while j < len(lines):
+                if seen.get(j, -1) >= out:
+                    break
+                seen[j] = out
+                u = lines[j]
+                if u.endswith(":"):
+                    j += 1
+                    continue
+                uop, _, urest = u.partition(" ")
+                if uop == "s_endpgm":
+                    bad.append(f"`{t}` (line {i}): a path reaches s_endpgm without a covering wait")
+                    break
+                if uop == "s_waitcnt":
+                    m = re.search(r"vmcnt\((\d+)\)", urest)
+                    if m and int(m.group(1)) <= out:
+                        break                       # data landed on this path
+                    j += 1
+                    continue
+                hit = dest & _vgprs(urest)
+                if hit:
+                    bad.append(f"`{u}` touches v{sorted(hit)} while `{t}` (hand-issued, line {i}) is in flight")
+                    break
+                if _VMEM.match(uop):
+                    out = min(out + 1, 64)
+                if uop == "s_branch" or uop.startswith("s_cbranch"):
+                    tgt = label_at.get(urest.strip())
+                    if tgt is not None:
+                        stack.append((tgt, out))
+                    if uop == "s_branch":
+                        break
+                j += 1
+    return checked, bad
+
+
+@pytest.mark.parametrize("src,flags,least", [("gemm_h16p.hip", [], 8), ("gemm_f32p.hip", ["-fno-slp-vectorize"], 8)])
+def test_hand_issued_loads_are_not_touched_before_their_wait(src, flags, least, tmp_path):
+    """The GPU memory fault of round 3 (gpurun_out/h16p_where.txt): an inline-asm global_load whose destination was a
+    temporary -- the compiler reused the registers before the data landed and the late write clobbered a pointer.  The
+    kernels now load into the long-lived destination and name it "+v" in the wait statement, but nothing in the language
+    stops a register-allocation change from putting a copy between load and wait again.  This is the guard: at ISA level,
+    on every path, nothing touches a hand-issued load's destination before the vmcnt wait that covers it."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    checked, bad = _hand_load_violations(_asm(src, flags, tmp_path))
+    assert checked >= least, checked
+    assert not bad, bad[:6]
+
+
+def test_hand_load_checker_catches_a_copy_and_a_missing_wait():
+    """The checker itself, on hand-made streams: a copy of the destination before the wait, a wait that is too shallow
+    (one younger load: vmcnt(1) covers, vmcnt(2) does not), a loop that carries the load across its back edge."""
+    ok = """
+    ;;#ASMSTART
+    global_load_dwordx4 v[4:7], v[2:3], off
+    ;;#ASMEND
+    v_add_u32_e32 v8, v9, v10
+    global_load_dword v11, v[2:3], off
+    s_waitcnt vmcnt(1)
+    v_mov_b32_e32 v12, v4
+    s_endpgm
+    """
+    assert _hand_load_violations(ok) == (1, [])
+    copy = ok.replace("v_add_u32_e32 v8, v9, v10", "v_mov_b32_e32 v8, v5")
+    assert len(_hand_load_violations(copy)[1]) == 1
+    assert len(_hand_load_violations(ok.replace("vmcnt(1)", "vmcnt(2)"))[1]) == 1
+    loop = """
+    .LBB0_1:
+    s_waitcnt vmcnt(0)
+    v_mov_b32_e32 v20, v6
+    ;;#ASMSTART
+    global_load_dwordx4 v[4:7], v[2:3], off
+    ;;#ASMEND
+    s_cbranch_scc1 .LBB0_1
+    s_waitcnt vmcnt(0)
+    s_endpgm
+    """
+    assert _hand_load_violations(loop) == (1, [])
+    assert len(_hand_load_violations(loop.replace("vmcnt(0)\n    v_mov", "vmcnt(1)\n    v_mov"))[1]) == 1
+    assert len(_hand_load_violations(loop.replace("s_waitcnt vmcnt(0)\n    s_endpgm", "s_endpgm"))[1]) == 1

@@ -41,10 +41,7 @@ for name, N, K, epi in SHAPES:
     outs, best = {}, {}
     for rnd in range(a.rounds + 1):
         for label, env in (("f32p", None), ("tile", "1")):
-            if env:
-                os.environ["VITSEG_NO_F32P"] = env
-            else:
-                os.environ.pop("VITSEG_NO_F32P", None)
+            _lib.set_option("no_f32p", 1 if env else 0)
             C = R0.clone() if epi == 2 else torch.zeros(M, N, device=dev)
 
             def fn():

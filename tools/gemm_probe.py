@@ -53,10 +53,7 @@ for name, N, K, epi in SHAPES:
     R = torch.randn(M, N, device=dev).to(torch.float32 if epi == 2 else dt) if epi in (2, 5) else None
     outs = {}
     for label, env in (("p8", None), ("old", "1")):
-        if env:
-            os.environ["VITSEG_NO_P8"] = env
-        else:
-            os.environ.pop("VITSEG_NO_P8", None)
+        _lib.set_option("no_p8", 1 if env else 0)
         C = R.clone() if epi == 2 else torch.zeros(M, N, device=dev, dtype=out_dt)
         call(A, W, b, C if epi == 2 else R, C, N, K, epi)
         outs[label] = C.float()
@@ -78,12 +75,12 @@ for name, N, K, epi in SHAPES:
     best = {"p8": 1e9, "old": 1e9, "vendor": 1e9}
     C = R.clone() if epi == 2 else torch.zeros(M, N, device=dev, dtype=out_dt)
     for _ in range(a.rounds):
-        os.environ.pop("VITSEG_NO_P8", None)
+        _lib.set_option("no_p8", 0)
         best["p8"] = min(best["p8"], timed(lambda: call(A, W, b, C if epi == 2 else R, C, N, K, epi)))
-        os.environ["VITSEG_NO_P8"] = "1"
+        _lib.set_option("no_p8", 1)
         best["old"] = min(best["old"], timed(lambda: call(A, W, b, C if epi == 2 else R, C, N, K, epi)))
         best["vendor"] = min(best["vendor"], timed(lambda: torch.matmul(A, W.t())))
-    os.environ.pop("VITSEG_NO_P8", None)
+    _lib.set_option("no_p8", 0)
     print(f"{name:18s} M={M} N={N} K={K}: p8 {best['p8'] * 1e6:7.1f} us {fl / best['p8'] / 1e12:7.1f} TF/s | old "
           f"{best['old'] * 1e6:7.1f} us {fl / best['old'] / 1e12:7.1f} | vendor plain {fl / best['vendor'] / 1e12:7.1f} | "
           f"max err p8 {err['p8']:.3e} old {err['old']:.3e} p8-old {same:.3e}", flush=True)
@@ -102,10 +99,7 @@ for name, Mo, No in [("dW fc2", 768, 3072), ("dW fc1", 3072, 768), ("dW o_proj",
                                                    zeros.data_ptr(), Mo, No, Kt, st))
     outs = {}
     for label, env in (("p8", None), ("old", "1")):
-        if env:
-            os.environ["VITSEG_NO_P8"] = env
-        else:
-            os.environ.pop("VITSEG_NO_P8", None)
+        _lib.set_option("no_p8", 1 if env else 0)
         fn()
         outs[label] = dW.clone()
     ref = dY[:, :64].float().T @ X.float()
@@ -113,12 +107,12 @@ for name, Mo, No in [("dW fc2", 768, 3072), ("dW fc1", 3072, 768), ("dW o_proj",
     fl = 2.0 * Mo * No * Kt
     best = {"p8": 1e9, "old": 1e9, "vendor": 1e9}
     for _ in range(a.rounds):
-        os.environ.pop("VITSEG_NO_P8", None)
+        _lib.set_option("no_p8", 0)
         best["p8"] = min(best["p8"], timed(fn))
-        os.environ["VITSEG_NO_P8"] = "1"
+        _lib.set_option("no_p8", 1)
         best["old"] = min(best["old"], timed(fn))
         best["vendor"] = min(best["vendor"], timed(lambda: torch.matmul(dY.t(), X)))
-    os.environ.pop("VITSEG_NO_P8", None)
+    _lib.set_option("no_p8", 0)
     print(f"{name:18s} M={Mo} N={No} K={Kt}: p8 {best['p8'] * 1e6:7.1f} us {fl / best['p8'] / 1e12:7.1f} TF/s | old "
           f"{best['old'] * 1e6:7.1f} us {fl / best['old'] / 1e12:7.1f} | vendor plain {fl / best['vendor'] / 1e12:7.1f} | "
           f"rel err p8 {err['p8']:.2e} old {err['old']:.2e}", flush=True)

@@ -67,6 +67,8 @@ def lib() -> C.CDLL:
         pcfg, psz = C.POINTER(CConfig), C.POINTER(C.c_size_t)
         l.vitseg_version.restype = i32
         l.vitseg_last_error.restype = C.c_char_p
+        l.vitseg_set_option.argtypes = [C.c_char_p, C.c_longlong]
+        l.vitseg_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_longlong)]
         l.vitseg_param_count.argtypes = [pcfg, psz]
         l.vitseg_param_offset.argtypes = [pcfg, i32, i32, psz, psz]
         l.vitseg_cast_params_bf16.argtypes = [vp, vp, sz, vp]
@@ -139,6 +141,33 @@ def check(rc: int) -> None:
     if rc == ESHAPE:
         raise ValueError(msg)
     raise RuntimeError(f"libvitseg error {rc}: {msg}")
+
+
+def set_option(name: str, value: int) -> None:
+    """Dispatcher switch (include/vitseg.h vitseg_set_option): e.g. set_option("no_f32p", 1)."""
+    check(lib().vitseg_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_longlong()
+    check(lib().vitseg_get_option(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
+class option:
+    """`with _lib.option("no_p8", 1): ...` -- the switch is restored on exit."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 def param_count(cfg: ViTSegConfig) -> int:

@@ -18,6 +18,24 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 
+// Dispatcher switches (A/B experiments, tests): a process-wide table read with one relaxed atomic load -- no getenv() on
+// the launch path.  Initial values come from the environment variable of the same name ("VITSEG_" + upper case) ONCE, when
+// the library is loaded; vitseg_set_option() (include/vitseg.h) changes them afterwards.
+enum Opt {
+    OPT_NO_F32P = 0,       // fp32 linears on gemm.hip's tile kernel instead of gemm_f32p.hip
+    OPT_NO_P8,             // 16-bit linears / weight gradients on the round-1 kernels instead of gemm_p8.hip
+    OPT_NO_H16P,           // bias-epilogue 16-bit linears on gemm_p8.hip instead of gemm_h16p.hip
+    OPT_NO_RAGGED_P8,      // a ragged last row tile never rides in the persistent kernel's last round
+    OPT_NO_DROPMASK,       // attention dropout hashed per element instead of read from precomputed keep-bit words
+    OPT_DROPW_LIMIT_MB,    // keep-bit words are kept per layer up to this many MiB in all (-1: the built-in limit)
+    OPT_UPSAMPLE_GLOBAL,   // upsample kernel without the LDS-staged source rows
+    OPT_BF16_TILES,        // round-1 16-bit tile choice: 0 by shape, 1 small (128x128), 2 large (256x128), 3 xl (256x256)
+    OPT_F32P_NOINL,        // gemm_f32p: every epilogue at its tile's end
+    OPT_GN,                // column-group width of the tile order (0: by shape)
+    OPT_COUNT
+};
+long opt(int id);
+
 #define VITSEG_CHECK_ARG(cond, code, ...) \
     do {                                  \
         if (!(cond)) {                    \

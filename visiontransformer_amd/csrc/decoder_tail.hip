@@ -349,7 +349,7 @@ int launch_upsample(const float* Z, float* logits, uint8_t* mask, int B, int C, 
     const int rows_out = whole ? (256 / quads) * UPR : 0;
     const size_t nr_max = (size_t)((double)rows_out * g / S) + 3;
     const size_t smem = (size_t)C * nr_max * g * sizeof(float);
-    if (whole && smem <= 48 * 1024 && !getenv("VITSEG_UPSAMPLE_GLOBAL"))
+    if (whole && smem <= 48 * 1024 && !opt(OPT_UPSAMPLE_GLOBAL))
         hipLaunchKernelGGL(upsample_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), smem, s, Z, logits, mask, B,
                            C, g, S);
     else

@@ -576,8 +576,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 }
 
 inline int env_gn() {  // experiments only: VITSEG_GN=<n> forces the column-group width of the tile order
-    static const int v = [] { const char* e = getenv("VITSEG_GN"); return e ? atoi(e) : 0; }();
-    return v;
+    return (int)opt(OPT_GN);
 }
 
 template <typename T, typename OutT, int AMODE, int EPI, int TA = 0, int TB = 0, int X3 = 0>
@@ -1206,7 +1205,7 @@ int launch_gemm_h16_impl(const GemmArgs& a_in, int amode, int epi, hipStream_t s
     // A ragged last row tile (the CLS rows) is free when it fits into the persistent kernel's last, partly empty round
     // (batch 32: 384 + 3 tiles of the N = 768 linears over 256 CUs): no side launch, no reducing kernel.
     if (amode == A_PLAIN && a_in.M % 256 != 0 && a_in.M % 256 <= 128 && gemm_p8_applies(a_in, epi) &&
-        gemm_p8_rounds(a_in.M, a_in.N) == gemm_p8_rounds(a_in.M - a_in.M % 256, a_in.N) && !getenv("VITSEG_NO_RAGGED_P8")) {
+        gemm_p8_rounds(a_in.M, a_in.N) == gemm_p8_rounds(a_in.M - a_in.M % 256, a_in.N) && !opt(OPT_NO_RAGGED_P8)) {
         a.thin_scratch = nullptr;
         if (want_cs) *p8_rows = a.M;
         return launch_gemm_p8(a, epi, s, std::is_same<T, f16_t>::value);
@@ -1254,9 +1253,9 @@ int launch_gemm_h16_impl(const GemmArgs& a_in, int amode, int epi, hipStream_t s
             default: return launch_one<T, float, A_PLAIN, EPI_RESADD>(t, s);
         }
     }
-    const char* force = getenv("VITSEG_BF16_TILES");  // "large" / "xl" / "small" for experiments
-    const bool xl = force ? force[0] == 'x' : (a.M >= 8192 && a.N >= 2048);
-    const bool large = force ? force[0] == 'l' : (!xl && a.M >= 4096 && a.K >= 2048);
+    const long force = opt(OPT_BF16_TILES);  // 1 small / 2 large / 3 xl for experiments
+    const bool xl = force ? force == 3 : (a.M >= 8192 && a.N >= 2048);
+    const bool large = force ? force == 2 : (!xl && a.M >= 4096 && a.K >= 2048);
     if (amode == A_PLAIN) {
         VITSEG_CHECK_ARG(a.lda % 8 == 0, VITSEG_EINVAL, "gemm_bf16: lda %% 8");
         switch (epi) {

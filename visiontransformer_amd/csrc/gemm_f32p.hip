@@ -514,8 +514,7 @@ int launch_f32p_one_i(const GemmArgs& a, hipStream_t s) {
 
 template <int EPI, bool DROP = false, bool AUX = false>
 int launch_f32p_one(const GemmArgs& a, hipStream_t s) {
-    static const bool noinl = getenv("VITSEG_F32P_NOINL") != nullptr;   // experiments: every epilogue at its tile's end
-    if (noinl || a.K < 4 * FK) return launch_f32p_one_i<EPI, DROP, AUX, false>(a, s);
+    if (opt(OPT_F32P_NOINL) || a.K < 4 * FK)   // (option: experiments, every epilogue at its tile's end) return launch_f32p_one_i<EPI, DROP, AUX, false>(a, s);
     return launch_f32p_one_i<EPI, DROP, AUX, true>(a, s);
 }
 
@@ -524,7 +523,7 @@ int launch_f32p_one(const GemmArgs& a, hipStream_t s) {
 // true when the persistent kernel takes this fp32 GEMM: plain A, whole 128-column tiles, whole 32-float K steps,
 // enough tiles to fill the chip, operands addressable through one 2 GiB buffer descriptor
 bool gemm_f32p_applies(const GemmArgs& a, int epi) {
-    if (getenv("VITSEG_NO_F32P")) return false;   // A/B against gemm.hip's kernel (tools/gemm_probe.py)
+    if (opt(OPT_NO_F32P)) return false;   // A/B against gemm.hip's kernel (tools/gemm_probe.py)
     const int ldw = a.ldw ? a.ldw : a.K;
     const size_t a_bytes = ((size_t)a.M + FM) * a.lda * 4, w_bytes = (size_t)a.N * ldw * 4;
     const int tiles = ((a.M + FM - 1) / FM) * (a.N / FN);

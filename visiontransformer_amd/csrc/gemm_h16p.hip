@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256) void gemm_h16p_kernel(const GemmArgs p) {
     const int tiles_m = (p.M + QT - 1) / QT, tiles_n = p.N / QT;
     const int ntiles = tiles_m * tiles_n;
     const int KT = p.K / 64;   // even (K % 128 == 0)
+    // A tile's bias is fetched by hand-issued loads in its second K step and read in the NEXT tile's first one; the counted
+    // waits only cover those loads once a further K step's DMA pieces are younger than them.  gemm_h16p_applies admits
+    // K >= 256 only; the kernel does not rely on its caller for that (tests/test_isa_cpu.py walks every path).
+    if (KT < 4) return;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int gn = (tiles_n % 4 == 0) ? 4 : (tiles_n % 3 == 0 ? 3 : (tiles_n >= 4 ? 4 : tiles_n));
     // tile order: column groups of gn tiles, row panels marching inside a group; the 32 blocks of one XCD take 32
@@ -498,7 +502,7 @@ int launch_h16p_t(const GemmArgs& a, hipStream_t s) {
 // of 64-deep K steps, at least 4 of them), the bias epilogue with 16-bit output, and a reduction short enough for the
 // epilogue to matter (K <= 1024: measured 1.10-1.13 x gemm_p8.hip at K = 768, 0.94-0.97 x at K >= 2304)
 bool gemm_h16p_applies(const GemmArgs& a, int epi) {
-    if (getenv("VITSEG_NO_H16P")) return false;   // A/B against gemm_p8.hip
+    if (opt(OPT_NO_H16P)) return false;   // A/B against gemm_p8.hip
     const size_t a_bytes = ((size_t)a.M + QT) * a.lda * 2, w_bytes = (size_t)a.N * (a.ldw ? a.ldw : a.K) * 2;
     return epi == EPI_BIAS && a.M >= 2048 && a.N % QT == 0 && a.K % 128 == 0 && a.K >= 256 && a.K <= 1024 && a.lda % 8 == 0 &&
            a.ldc % 8 == 0 && (a.ldw == 0 || a.ldw % 8 == 0) && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull &&

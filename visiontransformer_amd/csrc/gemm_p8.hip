@@ -510,7 +510,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
 
 // true when the 8-phase kernel takes this GEMM (plain A, whole 256-column tiles, an even number of 64-deep K steps)
 bool gemm_p8_applies(const GemmArgs& a, int epi) {
-    if (getenv("VITSEG_NO_P8")) return false;   // A/B against the previous kernels (tools/gemm_probe.py)
+    if (opt(OPT_NO_P8)) return false;   // A/B against the previous kernels (tools/gemm_probe.py)
     const size_t a_bytes = ((size_t)a.M + PT) * a.lda * 2, w_bytes = (size_t)a.N * (a.ldw ? a.ldw : a.K) * 2;
     return a.M >= 2048 && a.N % PT == 0 && a.K % 128 == 0 && a.K >= 256 && a.lda % 8 == 0 && a.ldc % 8 == 0 &&
            (a.ldw == 0 || a.ldw % 8 == 0) && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull && a.splitk <= 1 &&
@@ -575,7 +575,7 @@ int launch_gemm_p8(const GemmArgs& a, int epi, hipStream_t s, bool f16) {
 // Work items = output tiles x K slices, as close to one per CU as an even number of 64-token steps per slice allows;
 // each slice stores its fp32 partial tile and splitk_reduce sums the slices in a fixed order (deterministic).
 bool wgrad_p8_applies(const GemmArgs& a) {
-    if (getenv("VITSEG_NO_P8")) return false;
+    if (opt(OPT_NO_P8)) return false;
     return a.M % PT == 0 && a.N % PT == 0 && a.K >= 1024 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc == a.N &&
            (size_t)a.K * a.lda * 2 < 0x7fffffffull && (size_t)a.K * a.ldw * 2 < 0x7fffffffull;
 }

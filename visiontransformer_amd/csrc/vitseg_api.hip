@@ -1,8 +1,13 @@
 // C ABI of libvitseg.so (include/vitseg.h): parameter-arena layout, workspace planning and
 // the forward orchestration of the ViT segmentation hot path
 // (ViTSegmentationModel.forward, /root/reference/model/CE/classes.py:246-262).
+#include <ctype.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <strings.h>
+
+#include <atomic>
 
 #include <vector>
 
@@ -25,6 +30,35 @@ int hip_fail(hipError_t e, const char* what) {
     set_error("%s: %s", what, hipGetErrorString(e));
     return VITSEG_EHIP;
 }
+
+// ---- dispatcher switches (common.hpp Opt) ----
+static const char* const g_opt_names[OPT_COUNT] = {"no_f32p", "no_p8", "no_h16p", "no_ragged_p8", "no_dropmask",
+                                                   "dropw_limit_mb", "upsample_global", "bf16_tiles", "f32p_noinl", "gn"};
+static std::atomic<long> g_opts[OPT_COUNT];
+static int opt_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcasecmp(name, g_opt_names[i])) return i;
+    return -1;
+}
+static long opt_parse(int id, const char* text) {   // environment form: presence = 1 for the switches
+    if (id == OPT_BF16_TILES) return text[0] == 's' ? 1 : text[0] == 'l' ? 2 : text[0] == 'x' ? 3 : atol(text);
+    if (id == OPT_DROPW_LIMIT_MB || id == OPT_GN) return atol(text);
+    return 1;
+}
+static const bool g_opts_loaded = [] {   // once, at library load
+    for (int i = 0; i < OPT_COUNT; ++i) {
+        char env[64] = "VITSEG_";
+        for (size_t k = 0; g_opt_names[i][k] && k + 8 < sizeof(env); ++k) {
+            env[7 + k] = (char)toupper((unsigned char)g_opt_names[i][k]);
+            env[8 + k] = 0;
+        }
+        const char* e = getenv(env);
+        g_opts[i].store(e ? opt_parse(i, e) : (i == OPT_DROPW_LIMIT_MB ? -1 : 0), std::memory_order_relaxed);
+    }
+    return true;
+}();
+long opt(int id) { return g_opts[id].load(std::memory_order_relaxed); }
 
 namespace {
 
@@ -81,6 +115,19 @@ extern "C" {
 
 int vitseg_version(void) { return VITSEG_VERSION; }
 const char* vitseg_last_error(void) { return g_err; }
+
+int vitseg_set_option(const char* name, long long value) {
+    const int id = opt_index(name);
+    VITSEG_CHECK_ARG(id >= 0, VITSEG_EINVAL, "vitseg_set_option: unknown option '%s'", name ? name : "(null)");
+    g_opts[id].store((long)value, std::memory_order_relaxed);
+    return VITSEG_OK;
+}
+int vitseg_get_option(const char* name, long long* value) {
+    const int id = opt_index(name);
+    VITSEG_CHECK_ARG(id >= 0 && value, VITSEG_EINVAL, "vitseg_get_option: unknown option '%s'", name ? name : "(null)");
+    *value = opt(id);
+    return VITSEG_OK;
+}
 
 int vitseg_param_count(const vitseg_config* cfg, size_t* n_floats) {
     Shape s;
