@@ -22,7 +22,7 @@ BUF_TOKENS, BUF_LOWRES = 0, 1
  T_W1, T_B1, T_W2, T_B2, T_LNF_W, T_LNF_B, T_HEAD0_W, T_HEAD0_B, T_HEAD2_W, T_HEAD2_B, T_COUNT) = range(23)
 
 EXPORTS = [
-    "vitseg_version", "vitseg_last_error", "vitseg_param_count", "vitseg_param_offset", "vitseg_cast_params_bf16",
+    "vitseg_version", "vitseg_last_error", "vitseg_set_option", "vitseg_get_option", "vitseg_param_count", "vitseg_param_offset", "vitseg_cast_params_bf16",
     "vitseg_query_workspace", "vitseg_workspace_offset", "vitseg_forward", "vitseg_op_layernorm_f32",
     "vitseg_op_linear_f32", "vitseg_op_attention_f32", "vitseg_op_upsample_argmax",
     "vitseg_profile_enable", "vitseg_profile_collect", "vitseg_op_linear_bf16", "vitseg_op_attention_bf16",
