@@ -80,10 +80,6 @@ __global__ __launch_bounds__(256) void gemm_h16p_kernel(const GemmArgs p) {
     const int tiles_m = (p.M + QT - 1) / QT, tiles_n = p.N / QT;
     const int ntiles = tiles_m * tiles_n;
     const int KT = p.K / 64;   // even (K % 128 == 0)
-    // A tile's bias is fetched by hand-issued loads in its second K step and read in the NEXT tile's first one; the counted
-    // waits only cover those loads once a further K step's DMA pieces are younger than them.  gemm_h16p_applies admits
-    // K >= 256 only; the kernel does not rely on its caller for that (tests/test_isa_cpu.py walks every path).
-    if (KT < 4) return;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int gn = (tiles_n % 4 == 0) ? 4 : (tiles_n % 3 == 0 ? 3 : (tiles_n >= 4 ? 4 : tiles_n));
     // tile order: column groups of gn tiles, row panels marching inside a group; the 32 blocks of one XCD take 32
@@ -237,11 +233,14 @@ __global__ __launch_bounds__(256) void gemm_h16p_kernel(const GemmArgs p) {
                 }
         }
     };
+    // First point where the bias registers are read.  The loads were issued at the start of the tile's SECOND K step: at
+    // least that step's 16 DMA pieces are younger than the last of them on every path, so vmcnt(16) covers them whatever K
+    // is (with K >= 256, all this dispatcher admits, they landed K steps ago and the wait only asks for the ring's four
+    // oldest pieces one phase early).  The wait names the registers: nothing that reads them is scheduled above it
+    // (tests/test_isa_cpu.py checks the emitted code path by path).
     auto pin_bias = [&]() {
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-            for (int c4 = 0; c4 < 2; ++c4) asm volatile("" : "+v"(pbias4[hb][c4]));
+        asm volatile("s_waitcnt vmcnt(16)"
+                     : "+v"(pbias4[0][0]), "+v"(pbias4[0][1]), "+v"(pbias4[1][0]), "+v"(pbias4[1][1]) :: "memory");
     };
     // C is addressed through a buffer descriptor over the whole matrix: rows beyond M are out of range and their stores
     // are dropped, so a ragged tile needs no masks.  The descriptor is EMPTY until the block has finished its first tile:
