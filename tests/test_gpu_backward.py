@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import bf16_model as BM
 from oracle import vitseg_oracle as O
 from util import CASES, Golden
 from visiontransformer_amd import _lib, synth
@@ -13,13 +14,13 @@ from visiontransformer_amd.model import ViTSegmentationModel
 
 pytestmark = pytest.mark.gpu
 
-# bf16 gradient gates (per-tensor relative L2 error / cosine against the fp32 or fp64 gradient of the same step) = 2x the
-# worst case measured on MI355X in round 3 (the tests print it; gpurun_out/r03_gpu_all_*.log).  The noise grows with
-# depth: bf16 operands (2^-9) through 1-2 layers give <= 5.1e-2 / 0.9987, through 12 layers 0.14 / 0.991 (Tiny width) and
-# 0.22 / 0.976 (ViT-B/16 at 512x512, worst tensor; the gradient as a whole: see the full-depth test).
+# bf16 gradient gates.  Shallow models (<= 2 layers): per-tensor relative L2 error / cosine against the fp32 or fp64
+# gradient of the same step, bf16 operands (2^-9) through 1-2 layers give <= 5.1e-2 / 0.9987.  At depth no constant is
+# used: the distance of the HIP gradients from the exact ones is compared, tensor by tensor, with the distance of the
+# ROUNDING MODEL of the same step (oracle/bf16_model.py: fp64 arithmetic, rounded to bf16 where the HIP path stores or
+# multiplies a bf16) from the exact ones -- see _check_against_rounding_model.
 BF16_GRAD_REL, BF16_GRAD_COS = 0.10, 0.997            # <= 2 layers
-BF16_GRAD_REL_L12, BF16_GRAD_COS_L12 = 0.27, 0.982    # 12 layers, Tiny width
-BF16_GRAD_REL_B16, BF16_GRAD_COS_B16 = 0.45, 0.95     # 12 layers, ViT-B/16 at 512x512
+MODEL_RATIO, MODEL_SLACK = 1.3, 0.02                  # HIP error <= MODEL_RATIO * model error + MODEL_SLACK, per tensor
 DEV = "cuda:0"
 
 
@@ -316,6 +317,15 @@ def test_bf16_training_step_close_to_reference(name):
     loss.backward()
     from visiontransformer_amd.params import arena_views
     gv = arena_views(c, lm.model.arena.grad)
+    if c.num_hidden_layers > 2:
+        # at depth: exact fp64 gradients and the rounding model of the same step on the CPU, HIP held to the model's distance
+        sd = g.state_dict()
+        y = O.resize_target(g.targets(), (c.image_size, c.image_size))
+        leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+        O.ce_loss(O.forward(g.images().double(), leaf, c), y).backward()
+        _, g_model = BM.training_step(g.images(), y, sd, c)
+        _check_against_rounding_model(name, gv, {k: v.grad for k, v in leaf.items()}, g_model)
+        return
     # fp32 path on the same inputs = dense reference for cosine / relative-L2 (goldens only hold samples)
     lm32 = _build(g).train()
     l32 = lm32.training_step((g.images().to(DEV), g.targets().to(DEV)), 0)
@@ -330,9 +340,7 @@ def test_bf16_training_step_close_to_reference(name):
         rel = float((a - b).norm() / b.norm())
         cos = float((a @ b) / (a.norm() * b.norm()))
         worst, worst_cos = max(worst, rel), min(worst_cos, cos)
-        deep = c.num_hidden_layers > 2
-        assert cos > (BF16_GRAD_COS_L12 if deep else BF16_GRAD_COS) and rel < (BF16_GRAD_REL_L12 if deep else BF16_GRAD_REL), \
-            (k, rel, cos)
+        assert cos > BF16_GRAD_COS and rel < BF16_GRAD_REL, (k, rel, cos)
     print(f"{name}: bf16 vs fp32 gradients, worst per-tensor relative L2 error {worst:.3e}, worst cosine {worst_cos:.5f}")
 
 
@@ -447,10 +455,10 @@ def _relu_flip_tokens(stages, cfg, thr=2e-6, limit=16):
     return sorted(toks), int(near.shape[0])
 
 
-def _grad_check(cfg, arena_grad, leaf, precision, stages=None, bf16_gates=None):
+def _grad_check(cfg, arena_grad, leaf, precision, stages=None):
     from visiontransformer_amd.params import arena_views
     gv = arena_views(cfg, arena_grad)
-    rel_gate, cos_gate = bf16_gates or (BF16_GRAD_REL, BF16_GRAD_COS)
+    rel_gate, cos_gate = BF16_GRAD_REL, BF16_GRAD_COS
     worst, worst_cos, bad, worst_name = 0.0, 1.0, [], ""
     num, den = 0.0, 0.0
     exempt_rows, n_near = _relu_flip_tokens(stages, cfg) if stages is not None else ([], 0)
@@ -487,6 +495,40 @@ def _grad_check(cfg, arena_grad, leaf, precision, stages=None, bf16_gates=None):
           f"{n_near} head units within fp32 rounding of zero ({len(exempt_rows)} position-embedding rows set aside)")
     assert not bad, bad
     return worst, whole
+
+
+def _check_against_rounding_model(tag, hip, exact, model):
+    """bf16 HIP gradients `hip` (name -> tensor), exact fp64 gradients `exact`, gradients of the rounding model `model`
+    (oracle/bf16_model.py).  The model has no kernels, hence no kernel defects; its distance from the exact gradient is what
+    bf16 storage costs at this depth (rounding noise compounds through the layers, and the q/k gradients of near-uniform
+    attention are differences of nearly equal sums: test_attention_backward_bf16_is_its_rounding_model).  The HIP path
+    must sit at the same distance, per tensor: a kernel that loses part of a gradient adds its loss on top."""
+    rows, bad = [], []
+    num_h = num_e = den = 0.0
+    for k, r in exact.items():
+        if r is None or "pooler" in k:
+            continue
+        r = r.double().flatten()
+        h, e = hip[k].detach().cpu().double().flatten(), model[k].double().flatten()
+        if r.norm() < 1e-7:
+            if h.norm() >= 1e-4:
+                bad.append((k, "zero-gradient tensor", float(h.norm())))
+            continue
+        rel_h, rel_e = float((h - r).norm() / r.norm()), float((e - r).norm() / r.norm())
+        cos_h, cos_e = float((h @ r) / (h.norm() * r.norm())), float((e @ r) / (e.norm() * r.norm()))
+        num_h, num_e, den = num_h + float((h - r).pow(2).sum()), num_e + float((e - r).pow(2).sum()), den + float(r.pow(2).sum())
+        rows.append((rel_h / max(rel_e, 1e-12), k, rel_h, rel_e, cos_h, cos_e))
+        if not (rel_h <= MODEL_RATIO * rel_e + MODEL_SLACK and cos_h >= cos_e - MODEL_SLACK):
+            bad.append((k, rel_h, rel_e, cos_h, cos_e))
+    whole_h, whole_e = (num_h / den) ** 0.5, (num_e / den) ** 0.5
+    rows.sort(reverse=True)
+    worst = max(rows, key=lambda t: t[2])
+    print(f"{tag}: bf16 gradients vs fp64, HIP | rounding model: whole gradient {whole_h:.3e} | {whole_e:.3e}; "
+          f"worst tensor {worst[1]} {worst[2]:.3e} | {worst[3]:.3e} (cosine {worst[4]:.4f} | {worst[5]:.4f}); "
+          f"largest HIP/model ratios: " + ", ".join(f"{k} {a:.3f}/{b:.3f}" for _, k, a, b, _, _ in rows[:4]))
+    assert not bad, bad[:8]
+    assert whole_h <= MODEL_RATIO * whole_e + 0.005, (whole_h, whole_e)
+    return whole_h, whole_e
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -561,10 +603,14 @@ def test_training_step_vitb16_full_depth_512(p):
           f"bf16 {models['bf16'][1]:.6f}")
     assert abs(models["fp32"][1] - float(ref)) < 5e-6
     assert abs(models["bf16"][1] - float(ref)) < 5e-3
-    for prec in ("fp32", "bf16"):
-        _, whole = _grad_check(cfg, models[prec][0].arena.grad, leaf, prec, stages, (BF16_GRAD_REL_B16, BF16_GRAD_COS_B16))
-        # the gradient as ONE vector (what the optimizer sees): fp32 1e-5, bf16 a few per cent
-        assert whole < (1e-4 if prec == "fp32" else 0.15), (prec, whole)
+    _, whole = _grad_check(cfg, models["fp32"][0].arena.grad, leaf, "fp32", stages)
+    assert whole < 1e-4, whole                 # the gradient as ONE vector (what the optimizer sees)
+    # bf16: against the rounding model of the same step (same masks), tensor by tensor
+    from visiontransformer_amd.params import arena_views
+    loss_m, g_model = BM.training_step(x, y, sd, cfg, drop=masks)
+    assert abs(models["bf16"][1] - float(loss_m)) < 1e-3
+    _check_against_rounding_model(f"full-depth ViT-B/16 512x512, dropout {p}", arena_views(cfg, models["bf16"][0].arena.grad),
+                                  {k: v.grad for k, v in leaf.items()}, g_model)
 
 
 @pytest.mark.parametrize("B,Np,A,p", [(2, 256, 2, 0.0), (1, 1024, 2, 0.0), (2, 196, 3, 0.0), (1, 64, 1, 0.0), (2, 100, 2, 0.0),
@@ -620,6 +666,69 @@ def test_attention_backward_bf16(B, Np, A, p):
     # the CLS rows take the vector kernels: check them on their own
     cls = slice(B * Np, Mt)
     assert (got[cls] - ref[cls]).abs().max().item() < 2e-2 * ref[cls].abs().max().item()
+
+
+@pytest.mark.parametrize("Np,A,spread,p", [(1024, 2, 1.0, 0.0), (1024, 2, 0.3, 0.0), (1024, 1, 0.1, 0.0), (256, 3, 0.3, 0.0),
+                                           (1024, 1, 0.3, -0.1), (196, 2, 0.3, 0.1)])
+def test_attention_backward_bf16_is_its_rounding_model(Np, A, spread, p):
+    """Where the bf16 q/k gradients' large relative error at depth comes from, shown on the kernels themselves.  At random
+    init the tokens of an image are nearly alike by the middle of the encoder (attention is near-uniform), i.e. every key
+    is a common vector plus a small own part (`spread`).  Then dq_i = c sum_j dS_ij k_j is the small remainder of a sum whose
+    bulk, (sum_j dS_ij) k_mean, vanishes only in exact arithmetic: rounding dS to bf16 and taking delta from the bf16
+    context leave sum_j dS_ij != 0 and the error rides on the LARGE common part of the keys.  The test runs the three HIP
+    backward kernels and (a) exact fp64 autograd, (b) the rounding model (oracle/bf16_model.py attention_backward: the same
+    formulas with bf16(dS), bf16(P~) and delta from the kernel's own bf16 context), all on identical bf16 inputs:
+    the kernels must equal the MODEL to ~1e-2 per slot even where both are tens of per cent from exact arithmetic.
+    p < 0: dropout |p| through precomputed mask words."""
+    from dropout_ref import Masks
+    words, p = p < 0, abs(p)
+    B, hd = 1, 64
+    D, Mt, N = hd * A, B * Np + B, Np + 1
+    gen = torch.Generator().manual_seed(Np + A)
+    base = torch.randn(1, 3 * D, generator=gen) * 0.55
+    qkv = (base + spread * 0.55 * torch.randn(Mt, 3 * D, generator=gen)).to(torch.bfloat16)
+    dctx = (torch.randn(1, D, generator=gen) + torch.randn(Mt, D, generator=gen)).to(torch.bfloat16)
+    seed, stream_id = 0xBEEF1234, 3 * 8 + 1
+    qd, dd = qkv.to(DEV), dctx.to(DEV)
+    ctx = torch.zeros(Mt, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B * A * N, device=DEV)
+    scr = torch.empty(B * A * N, device=DEV)
+    dqkv = torch.full((Mt, 3 * D), float("nan"), device=DEV, dtype=torch.bfloat16)
+    mw = torch.empty(_lib.lib().vitseg_attention_dropmask_bytes(B, Np, A), dtype=torch.uint8, device=DEV) if words else None
+    _lib.check(_lib.lib().vitseg_op_attention_bwd_bf16(qd.data_ptr(), dd.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
+                                                       scr.data_ptr(), dqkv.data_ptr(), B, Np, A, p, seed, stream_id,
+                                                       mw.data_ptr() if words else None, _stream()))
+    got = dqkv.float().cpu().double()
+    assert torch.isfinite(got).all()
+    # reference token order (CLS first) <- patches-first rows; [1, A, N, hd] views
+    r = torch.cat([torch.tensor([B * Np]), torch.arange(0, Np)])
+
+    def heads(t):
+        return t[r].reshape(N, A, hd).transpose(0, 1)[None]
+
+    x = qkv.double()
+    q, k, v = [heads(x[:, i * D:(i + 1) * D]).clone().requires_grad_(True) for i in range(3)]
+    do = heads(dctx.double())
+    mask = Masks(p, seed, B, Np, A).attn(3, (B, A, N, N)).double() if p else None
+    prob = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1)
+    ((prob if mask is None else prob * mask) @ v * do).sum().backward()
+    exact = [t.grad for t in (q, k, v)]
+    # the model's backward on the kernel's OWN context and log-sum-exp (log2 units, CLS last -> natural log, CLS first)
+    o_k = heads(ctx.float().cpu().double())
+    lse_k = lse.cpu().double().reshape(B, A, N)
+    lse_k = (torch.cat([lse_k[..., Np:], lse_k[..., :Np]], dim=-1) * float(np.log(2.0)))[..., None]
+    with torch.no_grad():
+        model = BM.attention_backward(q.detach(), k.detach(), v.detach(), do, o_k, lse_k, mask)
+    line = []
+    for i, name in enumerate(("dq", "dk", "dv")):
+        gk = heads(got[:, i * D:(i + 1) * D])
+        vs_model = float((gk - BM.rb(model[i])).norm() / model[i].norm())
+        vs_exact = float((gk - exact[i]).norm() / exact[i].norm())
+        model_vs_exact = float((model[i] - exact[i]).norm() / exact[i].norm())
+        line.append(f"{name}: kernel-model {vs_model:.2e}, kernel-exact {vs_exact:.2e}, model-exact {model_vs_exact:.2e}")
+        # the output rounding alone is 2^-9 (rel. L2 ~2e-3); the rest is fp32 vs fp64 inside: a few roundings of dS flip
+        assert vs_model < 1e-2 + 0.05 * model_vs_exact, (name, vs_model, vs_exact, model_vs_exact)
+    print(f"Np {Np}, heads {A}, own part {spread}, dropout {p}{' (words)' if words else ''}: " + "; ".join(line))
 
 
 def test_resume_restores_optimizer_state(tmp_path):

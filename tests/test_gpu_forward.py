@@ -235,6 +235,54 @@ def test_vit_large_width_tiled_1024(precision, margin):
         assert (lg.cpu() - O.forward(big[:, :, :512, :512], sd, cfg)).abs().max().item() < 1e-3
 
 
+@pytest.fixture(scope="module")
+def vit_large_full_depth():
+    """BASELINE configs[4]'s model at FULL depth: ViT-L/16 = D 1024, L 24, A 16, I 3072 (model/CE/classes.py:224-238 with
+    hidden_size 1024 / 24 layers / 16 heads), one 512x512 tile, batch 1, and the oracle's fp64 forward of it.  With
+    random-init weights the two class logits sit ~0.2 apart everywhere (one class wins every pixel), so the bias of class 1
+    is shifted by the median logit difference: the decision boundary then runs through the image and the mask test means
+    something (logits are affine in that bias; the shifted reference is recomputed, not derived)."""
+    cfg = ViTSegConfig(2, 16, 1024, 24, 16, image_size=512)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=77).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 1, seed=3))
+    torch.set_num_threads(16)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = O.forward(x.double(), sd64, cfg)
+        shift = float((ref[:, 0] - ref[:, 1]).median())
+        sd["seg_head.2.bias"] = sd["seg_head.2.bias"].clone()
+        sd["seg_head.2.bias"][1] += shift
+        sd64["seg_head.2.bias"] = sd["seg_head.2.bias"].double()
+        low = {}
+        ref = O.forward(x.double(), sd64, cfg, low)
+    return cfg, sd, x, ref
+
+
+@pytest.mark.parametrize("precision,tol_logits,tol_mask", [("fp32", 1e-3, 0.0), ("fp16", 1e-3, 1e-3), ("bf16", 3e-2, 1.5e-2)])
+def test_vit_large_full_depth_512(vit_large_full_depth, precision, tol_logits, tol_mask):
+    """All 24 layers of ViT-L/16 on the GPU against the fp64 oracle: logits within the north_star's 1e-3 for fp32 (and for
+    fp16, the format configs[4] names), 3e-2 for bf16; masks identical wherever the measured logit error cannot flip the
+    decision (fp32, `O.mask_stable`), mismatch <= 0.1 % (fp16) / 1.5 % (bf16) of a mask that is half class 0, half class 1."""
+    cfg, sd, x, ref = vit_large_full_depth
+    m = ViTSegmentationModel(2, 16, 1024, 24, 16, image_size=512, precision=precision, device=DEV).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        mask, got = m.predict_mask(x.to(DEV), return_logits=True)
+    err = (got.cpu().double() - ref).abs().max().item()
+    ref_mask = O.predict_mask(ref.float()).numpy()
+    frac1 = float(ref_mask.mean())
+    mism = float((mask.cpu().numpy() != ref_mask).mean())
+    print(f"ViT-L/16 full depth 512x512, {precision}: logits max-abs err {err:.3e}, mask mismatch {mism:.4%} "
+          f"(class 1 on {frac1:.1%} of the pixels)")
+    assert 0.3 < frac1 < 0.7
+    assert err < tol_logits, err
+    if precision == "fp32":
+        stable = O.mask_stable(ref.float(), 2.0 * err + 1e-7).numpy()
+        assert ((mask.cpu().numpy() != ref_mask) & stable).sum() == 0 and (~stable).mean() < 2e-3
+    else:
+        assert mism <= tol_mask, mism
+
+
 @pytest.mark.parametrize("P,D,A", [(4, 512, 8), (8, 1024, 16), (16, 512, 8)])
 def test_reference_configuration_grid(P, D, A):
     """The reference sweeps patch sizes 16 / 8 / 4 and widths 512 / 768 / 1024 (testViTModel.py:73-83).  The corners the
