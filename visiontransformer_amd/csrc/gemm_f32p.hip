@@ -514,7 +514,8 @@ int launch_f32p_one_i(const GemmArgs& a, hipStream_t s) {
 
 template <int EPI, bool DROP = false, bool AUX = false>
 int launch_f32p_one(const GemmArgs& a, hipStream_t s) {
-    if (opt(OPT_F32P_NOINL) || a.K < 4 * FK)   // (option: experiments, every epilogue at its tile's end) return launch_f32p_one_i<EPI, DROP, AUX, false>(a, s);
+    if (opt(OPT_F32P_NOINL) || a.K < 4 * FK)   // (option: experiments, every epilogue at its tile's end)
+        return launch_f32p_one_i<EPI, DROP, AUX, false>(a, s);
     return launch_f32p_one_i<EPI, DROP, AUX, true>(a, s);
 }
 
