@@ -15,6 +15,8 @@ int hip_fail(hipError_t e, const char* what) {
     return 1;
 }
 void set_error(const char* fmt, ...) { fprintf(stderr, "%s\n", fmt); }
+static long g_probe_opts[OPT_COUNT] = {};   // the dispatcher switches of common.hpp, local to this harness
+long opt(int id) { return g_probe_opts[id]; }
 int device_num_cus() { return 256; }
 }   // namespace vitseg
 

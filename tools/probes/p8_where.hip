@@ -15,6 +15,8 @@ int hip_fail(hipError_t e, const char* what) {
     return 1;
 }
 void set_error(const char* fmt, ...) { fprintf(stderr, "%s\n", fmt); }
+static long g_probe_opts[OPT_COUNT] = {};   // the dispatcher switches of common.hpp, local to this harness
+long opt(int id) { return g_probe_opts[id]; }
 int launch_splitk_reduce(const float*, float*, size_t, int, hipStream_t) { return 0; }
 }   // namespace vitseg
 
@@ -54,9 +56,10 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const bool both = getenv("P8_WHERE_BOTH") != nullptr;
+    if (getenv("P8_WHERE_NO_H16P")) vitseg::g_probe_opts[vitseg::OPT_NO_H16P] = 1;   // every NT shape on gemm_p8.hip
     for (int pass = 0; pass < (both ? 2 : 1); ++pass) {
     if (both) {
-        if (pass == 0) setenv("VITSEG_NO_H16P", "1", 1); else unsetenv("VITSEG_NO_H16P");
+        vitseg::g_probe_opts[vitseg::OPT_NO_H16P] = pass == 0 ? 1 : 0;
         printf("-- %s\n", pass == 0 ? "gemm_p8 (VITSEG_NO_H16P=1)" : "gemm_h16p");
     }
     for (const Shape& s : shapes) {
@@ -81,7 +84,10 @@ int main(int argc, char** argv) {
             hipEventElapsedTime(&ms, e0, e1);
             if (rnd && ms / 10 < best) best = ms / 10;
         }
-        printf("%-30s %8.1f us  %7.1f TFLOP/s\n", s.name, best * 1e3, 2.0 * M * s.N * s.K / (best * 1e-3) * 1e-12);
+        // per 64-deep K step of a 256 x 256 tile, one tile per CU and round (256 CUs): what the main loop costs
+        const double ksteps = (double)((M + 255) / 256) * (s.N / 256) / 256.0 * (s.K / 64);
+        printf("%-30s %8.1f us  %7.1f TFLOP/s  %6.3f us per K step (%.0f steps)\n", s.name, best * 1e3,
+               2.0 * M * s.N * s.K / (best * 1e-3) * 1e-12, best * 1e3 / ksteps, ksteps);
     }
     }
     {   // weight gradient (TT form): dW[768][3072] over 65536 tokens

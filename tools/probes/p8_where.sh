@@ -37,6 +37,14 @@ nostore = rep(s, "                    if (grow < p.M) {\n                       
               "                    if (grow < 0) {\n                        if (EPI == EPI_GELU && p.aux) *(uint4*)((T*)p.aux + o) = ha;\n                        *(uint4*)(Cbase + o) = h;\n                    }")
 nostore = rep(nostore, "if (grow < p.M) *(f32x4*)((float*)Cbase + o)", "if (grow < 0) *(f32x4*)((float*)Cbase + o)")
 w("nostore", nostore)
+# tile-transition ablations on top of noepi: (a) the epilogue bracket barriers that re-align the two wave rows,
+# (b) the tile coordinates without integer divisions (valid for 256 row tiles: M = 65536)
+notilesync = rep(noepi, "            if (wr == 0) P8_BAR();\n", "")
+notilesync = rep(notilesync, "            if (wr == 1) P8_BAR();\n            zero_acc();", "            zero_acc();")
+w("noepi_notilesync", notilesync)
+nocoord = rep(noepi, "    const int t = logical_item(round, tiles_m * tiles_n);\n    const int gsz = tiles_m * gn, ngroups = (tiles_n + gn - 1) / gn;",
+              "    const int t = round * (int)gridDim.x + (int)blockIdx.x;\n    if (tiles_m == 256) { TileCoord q; q.m0 = (t & 255) * PT; q.n0 = (t >> 8) * PT; q.split = 0; return q; }\n    const int gsz = tiles_m * gn, ngroups = (tiles_n + gn - 1) / gn;")
+w("noepi_nocoord", nocoord)
 nobar = rep(noepi, "        __builtin_amdgcn_s_barrier();         \\\n", "        ;         \\\n")
 w("noepi_nobarrier", nobar)
 nodma = rep(noepi, '"s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds"', '""')

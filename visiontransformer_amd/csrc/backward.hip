@@ -1,6 +1,8 @@
 // Backward-pass kernels that are not GEMMs or attention (a13: what autograd runs behind
 // LightningViTModel.training_step, /root/reference/model/CE/classes.py:276-285, and Adam, :296-297).
 // All reductions are deterministic: per-block partial sums in a scratch buffer, finished in a fixed order.
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace vitseg {
@@ -100,14 +102,14 @@ __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __rest
 // y = xhat * w + b, xhat = (x - mu) * rstd.  With gw = g * w:
 //   dx = rstd * (gw - mean(gw) - xhat * mean(gw * xhat));   dw = sum_rows g * xhat;   db = sum_rows g.
 // dres_out[row] = (dres_in ? dres_in[row] : 0) + dx  (the residual branch's gradient is added here).
-// One wave per row (statistics recomputed from the saved input), 64 rows per block; the block's dw/db
+// One wave per row (statistics recomputed from the saved input), ~64 rows per block; the block's dw/db
 // partial sums go to partial[block][SETS][D].
 // BR (branch output): the gradient that enters the NEXT dropped residual branch of the backward walk is
 // mask * dres_out (hidden dropout of that branch, DropArgs br_drop; thresh 0 = no dropout) -- written here as bf16
 // (the operand format of the branch's GEMMs) together with its column sums (the branch's bias gradient, third
 // partial set), so neither a dropout/cast pass nor a column-sum pass has to re-read dres_out.
 template <int NV, typename GT, bool BR>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, NV <= 3 ? 3 : 2) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const GT* __restrict__ g, const float* dres_in,
                                                             float* dres_out, float* __restrict__ partial, int rows,
                                                             int D, float eps, bf16_t* __restrict__ br_out,
@@ -124,33 +126,44 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) dw[i][e] = db[i][e] = 0.f;
         if constexpr (BR) dbr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // the next row's x / g / dres_in are requested before the current row's four dependent wave reductions, so a wave
-    // always has one row of loads in flight (the rows of a wave are 4 apart)
-    f32x4 nx[NV], ng[NV], nd[NV];
+    // Rows are dealt evenly over the grid (block b: rows [b R / G, (b + 1) R / G), wave w every fourth of them): the
+    // launcher sizes the grid to what is resident at once, so no last partial round of a few blocks runs alone
+    // (65 600 rows as 1 025 blocks of 64 on 512 resident slots was 2.002 rounds).
+    // The next row's x / g are requested before the current row's four dependent wave reductions, so a wave always has
+    // a row of loads in flight; g stays packed while it waits (16-bit GT: 2 registers per 4 values), and the residual
+    // gradient of the CURRENT row is requested at the row's start and only read by its last stage -- its latency hides
+    // behind the reductions without a second set of staging registers (192 -> 165 VGPRs: 3 waves per SIMD).
+    constexpr bool G16 = sizeof(GT) == 2;
+    typedef typename std::conditional<G16, uint2, f32x4>::type gpack_t;
+    f32x4 nx[NV];
+    gpack_t ng[NV];
     auto fetch = [&](int row) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = min(lane + 64 * i, nv - 1);
             nx[i] = ((const f32x4*)(x + (size_t)row * D))[c];
-            ng[i] = ld4(g + (size_t)row * D + 4 * c);
-            if (dres_in) nd[i] = ((const f32x4*)(dres_in + (size_t)row * D))[c];
+            ng[i] = *(const gpack_t*)(g + (size_t)row * D + 4 * c);
         }
     };
-    {
-        const int row0 = blockIdx.x * 64 + wave;
-        if (row0 < rows) fetch(row0);
-    }
-    for (int it = 0; it < 16; ++it) {
-        const int row = blockIdx.x * 64 + it * 4 + wave;
-        if (row >= rows) break;  // wave-uniform
+    const int row_begin = (int)((long long)blockIdx.x * rows / (int)gridDim.x);
+    const int row_end = (int)((long long)(blockIdx.x + 1) * rows / (int)gridDim.x);
+    if (row_begin + wave < row_end) fetch(row_begin + wave);
+    for (int row = row_begin + wave; row < row_end; row += 4) {   // wave-uniform
         f32x4 xv[NV], gv[NV], dv[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             xv[i] = nx[i];
-            gv[i] = ng[i];
-            dv[i] = nd[i];
+            if constexpr (G16) {
+                gv[i] = f32x4{H16<bf16_t>::lo(ng[i].x), H16<bf16_t>::hi(ng[i].x), H16<bf16_t>::lo(ng[i].y), H16<bf16_t>::hi(ng[i].y)};
+            } else {
+                gv[i] = ng[i];
+            }
         }
-        if (it + 1 < 16 && row + 4 < rows) fetch(row + 4);
+        if (row + 4 < row_end) fetch(row + 4);
+        if (dres_in) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) dv[i] = ((const f32x4*)(dres_in + (size_t)row * D))[min(lane + 64 * i, nv - 1)];
+        }
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -539,7 +552,11 @@ int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is
                          hipStream_t s, void* br_out, DropArgs br_drop, float* br_dbias) {
     VITSEG_CHECK_ARG(D % 4 == 0 && D <= 1024, VITSEG_ESHAPE, "layernorm_bwd: D=%d must be a multiple of 4, <= 1024", D);
     VITSEG_CHECK_ARG(!br_out || (g_is_bf16 && br_dbias), VITSEG_EINVAL, "layernorm_bwd: branch output needs bf16 g + dbias");
-    const int blocks = (rows + 63) / 64, nvl = (D / 4 + 63) / 64;
+    // grid: 64-row blocks, capped at what is resident at once (3 blocks of 4 waves per CU up to D = 768: <= 168 VGPRs
+    // by __launch_bounds__, 36 KiB of LDS each; 2 beyond)
+    const int nvl = (D / 4 + 63) / 64;
+    const int cap = (nvl <= 3 ? 3 : 2) * device_num_cus();
+    const int blocks = (rows + 63) / 64 < cap ? (rows + 63) / 64 : cap;
 #define VITSEG_LNB(NV)                                                                                            \
     do {                                                                                                          \
         if (br_out)                                                                                               \
