@@ -45,6 +45,12 @@ w("noepi_notilesync", notilesync)
 nocoord = rep(noepi, "    const int t = logical_item(round, tiles_m * tiles_n);\n    const int gsz = tiles_m * gn, ngroups = (tiles_n + gn - 1) / gn;",
               "    const int t = round * (int)gridDim.x + (int)blockIdx.x;\n    if (tiles_m == 256) { TileCoord q; q.m0 = (t & 255) * PT; q.n0 = (t >> 8) * PT; q.split = 0; return q; }\n    const int gsz = tiles_m * gn, ngroups = (tiles_n + gn - 1) / gn;")
 w("noepi_nocoord", nocoord)
+# main loop without any fragment read (the registers keep whatever they hold): MFMAs + DMA + barriers only
+noread = rep(noepi, "        for (int mt = 0; mt < 4; ++mt)\n#pragma unroll\n            for (int ks = 0; ks < 2; ++ks) {\n                if (TT)\n                    xa[mt][ks]",
+             "        for (int mt = 0; mt < (p.M < 0 ? 4 : 0); ++mt)\n#pragma unroll\n            for (int ks = 0; ks < 2; ++ks) {\n                if (TT)\n                    xa[mt][ks]")
+noread = rep(noread, "        for (int nt = 0; nt < 2; ++nt)\n#pragma unroll\n            for (int ks = 0; ks < 2; ++ks) {\n                if (TT)\n                    w[nt][ks]",
+             "        for (int nt = 0; nt < (p.M < 0 ? 2 : 0); ++nt)\n#pragma unroll\n            for (int ks = 0; ks < 2; ++ks) {\n                if (TT)\n                    w[nt][ks]")
+w("noepi_noread", noread)
 nobar = rep(noepi, "        __builtin_amdgcn_s_barrier();         \\\n", "        ;         \\\n")
 w("noepi_nobarrier", nobar)
 nodma = rep(noepi, '"s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds"', '""')

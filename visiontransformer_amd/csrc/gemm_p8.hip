@@ -29,8 +29,6 @@
 // Roofline: MFMA bf16/f16 dense 2.5 PFLOP/s; algorithmic work 2 M N K per launch.
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "kernels.hpp"
 
 namespace vitseg {
@@ -259,12 +257,9 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
     };
     bf16x8 xa[4][2];          // activation fragments of the current A-half: [m tile][k step]
     bf16x8 wx[2][2], wy[2][2];  // weight fragments of the two B-halves (roles alternate per K step)
-    // A fragments [m tile][k step] of one half; m tiles [mt0, mt1) -- the phase's load interval reads the first 4 - LATE m
-    // tiles, the last LATE are read INSIDE the phase's MFMA interval (see mfma_quad)
-    auto read_a = [&](int region, auto mt0_tag, auto mt1_tag) {
-        constexpr int MT0 = decltype(mt0_tag)::value, MT1 = decltype(mt1_tag)::value;
+    auto read_a = [&](int region) {
 #pragma unroll
-        for (int mt = MT0; mt < MT1; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (TT)
@@ -291,39 +286,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // Balance of the two kinds of barrier interval.  A phase = load interval (fragment reads + 2 DMA pieces + counted wait)
-    // | barrier | MFMA interval (16 MFMAs = 256 cycles) | barrier, the two wave rows one interval apart, so an interval
-    // lasts max(load of one row, MFMAs of the other).  Phases 0 and 2 read a whole A half (8 fragments), phases 1 and 3 a
-    // B half (4): measured (profiles/r04_pmc_gemm16.json, K = 3072: 2 225 cycles per K step = 4 x 300 + 4 x 256) the
-    // A-phase load interval overruns the partner's MFMAs by ~45 cycles, the B-phase one does not.  So the last LATE m tiles
-    // of an A half are read at the START of the phase's own MFMA interval instead (behind the barrier: the half was waited
-    // for long ago and is only refilled two phases later) and their MFMAs run last -- both kinds of load interval then
-    // carry 4 fragments.  Each accumulator still sums k steps 0, 1 in that order: results are bit-identical.
-    constexpr int LATE = 2;
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 4 - LATE> IE;
-    typedef std::integral_constant<int, 4> I4;
-    auto mfma_quad = [&](int ha, int hb, bf16x8 (&w)[2][2], int late_region) {
+    auto mfma_quad = [&](int ha, int hb, bf16x8 (&w)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
-        if (late_region >= 0) read_a(late_region, IE{}, I4{});
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int mt = 0; mt < 4 - LATE; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[ha * 4 + mt][hb * 2 + nt] = Mfma16<T>::run(w[nt][ks], xa[mt][ks], acc[ha * 4 + mt][hb * 2 + nt]);
-        if (late_region >= 0) {   // the late reads go one per MFMA under the first MFMAs (pinned: not sunk to their use)
-#pragma unroll
-            for (int i = 0; i < LATE * 2 * (TT ? 2 : 1); ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 4 - LATE; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     acc[ha * 4 + mt][hb * 2 + nt] = Mfma16<T>::run(w[nt][ks], xa[mt][ks], acc[ha * 4 + mt][hb * 2 + nt]);
@@ -488,25 +456,25 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
 #define P8_KSTEP(s, w0, w1, G)                                                                       \
     do {                                                                                             \
         /* phase 0: quadrant (a0, b0) */                                                             \
-        read_a(4 * (s) + 0, I0{}, IE{});                                                             \
+        read_a(4 * (s) + 0);                                                                         \
         issue_half(cur0, 2, 4 * ((s) ^ 1) + 2);                                                         \
         P8_VMCNT(8);                                                                                 \
         P8_BAR();                                                                                    \
-        mfma_quad(0, 0, w0, 4 * (s) + 0);                                                            \
+        mfma_quad(0, 0, w0);                                                                         \
         P8_BAR();                                                                                    \
         /* phase 1: (a0, b1) */                                                                      \
         read_b(w1, 4 * (s) + 2);                                                                     \
         issue_half(cur0, 3, 4 * ((s) ^ 1) + 3);                                                         \
         P8_VMCNT(8);                                                                                 \
         P8_BAR();                                                                                    \
-        mfma_quad(0, 1, w1, -1);                                                                     \
+        mfma_quad(0, 1, w1);                                                                         \
         P8_BAR();                                                                                    \
         /* phase 2: (a1, b1) */                                                                      \
-        read_a(4 * (s) + 3, I0{}, IE{});                                                             \
+        read_a(4 * (s) + 3);                                                                         \
         issue_half(cur1, 0, 4 * (s) + 0);                                                               \
         P8_VMCNT(6);                                                                                 \
         P8_BAR();                                                                                    \
-        mfma_quad(1, 1, w1, 4 * (s) + 3);                                                            \
+        mfma_quad(1, 1, w1);                                                                         \
         P8_BAR();                                                                                    \
         /* phase 3: (a1, b0); the next step's B0 goes into the buffer b1 just vacated */             \
         read_b(w1, 4 * ((s) ^ 1) + 1);                                                               \
@@ -515,7 +483,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
         advance(cur1);                                                                               \
         P8_VMCNT(8);                                                                                 \
         P8_BAR();                                                                                    \
-        mfma_quad(1, 0, w0, -1);                                                                     \
+        mfma_quad(1, 0, w0);                                                                         \
         P8_BAR();                                                                                    \
     } while (0)
 
