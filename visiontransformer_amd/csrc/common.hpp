@@ -176,40 +176,32 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// exact (erf) GELU, activations.py:78-83
-__device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
-
-// The same function without control flow: libm's erff (ROCm device library, __ocml_erf_f32) branches on |x| < 1, and a
-// wave whose lanes disagree runs both sides plus the branch bookkeeping.  Both polynomials are evaluated here with the
-// library's coefficients and operation order and one select picks the result: BIT-IDENTICAL to erff(x) for every input
-// (tools/probes/erff_nb_check.hip sweeps all 2^32 floats), straight-line code the scheduler can place between MFMAs.
-__device__ __forceinline__ float erff_nb(float x) {
-#pragma clang fp contract(off)   // every fused multiply-add below is spelled out; ph - e must stay a subtraction
-    const float ax = fabsf(x), t = x * x;
-    float ps = fmaf(t, __uint_as_float(0xba1345e1u), __uint_as_float(0x3ba10414u));
-    ps = fmaf(t, ps, __uint_as_float(0xbcdac9b8u));
-    ps = fmaf(t, ps, __uint_as_float(0x3de703beu));
-    ps = fmaf(t, ps, __uint_as_float(0xbec09330u));
-    ps = fmaf(t, ps, __uint_as_float(0x3e0375d0u));
-    const float small = fmaf(ax, ps, ax);
-    float pb = fmaf(ax, __uint_as_float(0x378e98abu), __uint_as_float(0xb9c68948u));
-    pb = fmaf(ax, pb, __uint_as_float(0x3b7cd369u));
-    pb = fmaf(ax, pb, __uint_as_float(0xbcc618b2u));
-    pb = fmaf(ax, pb, __uint_as_float(0x3dda74e4u));
-    pb = fmaf(ax, pb, __uint_as_float(0x3f228afdu));
-    pb = fmaf(ax, pb, __uint_as_float(0x3e03c728u));
-    pb = fmaf(ax, pb, ax);
-    // 1 - exp(-pb) with the library's expf steps (49-bit log2 e product, rndne, v_exp_f32, ldexp) minus its two range
-    // guards: -pb is clamped at -104 instead (exp underflows to less than half an ulp of 1 either way), and a NaN takes
-    // the `small` side of the select, which propagates it
-    const float nx = fmaxf(-pb, -104.0f);
-    const float ph = nx * 0x1.715476p+0f;
-    const float pl = fmaf(nx, 0x1.4ae0bep-26f, fmaf(nx, 0x1.715476p+0f, -ph));
-    const float e = rintf(ph);
-    const float big = 1.0f - ldexpf(__builtin_amdgcn_exp2f(ph - e + pl), (int)e);
-    return copysignf(ax >= 1.0f ? big : small, x);
+// exact (erf) GELU, activations.py:78-83:  gelu(u) = u Phi(u),  Phi(u) = (1 + erf(u / sqrt 2)) / 2.
+// Evaluated through the COMPLEMENTARY error function of a = |u| / sqrt 2,  erfc(a) = 2^(-a Q(a)):
+//     Phi(u) = 1 - erfc(a) / 2  (u >= 0),   erfc(a) / 2  (u < 0),
+// Q = an 8th-degree polynomial fitted (weighted minimax on [0, 5], tools/fit_gelu_erfc.py) to -log2(erfc(a)) / a.
+// Why not libm's erff (what rounds 1-3 used, through a branch-free restatement): 1 + erf(x) cancels for x < 0, so that
+// form is good to 6e-8 ABSOLUTE in Phi -- 8e-6 of the result at u = -3 -- and costs ~34 vector instructions (two
+// polynomials, an emulated expf, a select); erfc keeps the tail's RELATIVE precision and is one polynomial, one v_exp_f32
+// and a select: 18 instructions.  On the fp32 path every one of them is time added to the fp32 MFMAs.
+// Error against fp64 over ALL 2^32 inputs (tools/probes/gelu_check.hip): see DESIGN section 3; |error| <= 0.7e-6 of
+// max(|gelu|, 1e-2), median 0.4 ulp -- below the libm form's on both counts.  gelu(+inf) = +inf, NaN stays NaN.
+__device__ __forceinline__ float gelu_erf(float u) {
+#pragma clang fp contract(off)   // every fused multiply-add is spelled out: all kernels must agree bit for bit
+    const float a = fminf(fabsf(u) * 0.70710678118654752440f, 5.0f);   // erfc(5) = 1.5e-12: nothing left of Phi beyond
+    float q = __uint_as_float(0xb6e5811du);
+    q = fmaf(a, q, __uint_as_float(0x38d55d79u));
+    q = fmaf(a, q, __uint_as_float(0xba2329bbu));
+    q = fmaf(a, q, __uint_as_float(0x3ae4efa2u));
+    q = fmaf(a, q, __uint_as_float(0x3a233c25u));
+    q = fmaf(a, q, __uint_as_float(0xbce796e6u));
+    q = fmaf(a, q, __uint_as_float(0x3e181a64u));
+    q = fmaf(a, q, __uint_as_float(0x3f6b1c07u));
+    q = fmaf(a, q, __uint_as_float(0x3fd05f5fu));
+    const float e = __builtin_amdgcn_exp2f(-(a * q));                  // erfc(a)
+    const float w = u >= 0.f ? fmaf(e, -0.5f, 1.0f) : 0.5f * e;        // Phi(u); a NaN takes the second side and stays one
+    return u * w;
 }
-__device__ __forceinline__ float gelu_erf_nb(float u) { return 0.5f * u * (1.0f + erff_nb(u * 0.70710678118654752440f)); }
 
 // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
 __device__ __forceinline__ float gelu_erf_grad(float u) {

@@ -43,8 +43,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // DROP: hidden dropout on the residual branch compiled in (fp32 training forward)
 // AUX: the GELU epilogue also stores the pre-activation (fp32 training forward)
-// INL: a finished tile is written under the first K step of the block's next tile (kstep_first; GELU's ~32 VALU per
-//      value are 4 x what that step's MFMAs hide, so the step is VALU-bound there and takes about two plain steps)
+// INL: a finished tile is written under the first K step of the block's next tile (kstep_first; GELU's ~18 VALU per
+//      value are twice what that step's MFMAs hide, so the step is VALU-bound there)
 template <int EPI, bool DROP, bool AUX, bool INL>
 __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ring | per-wave slabs
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
     auto epi_value = [&](float x, float& pre, int grow, int gcol) {
         if (EPI == EPI_GELU) {
             pre = x;                            // saved pre-activation (fp32 training)
-            x = gelu_erf_nb(x);                // = gelu_erf(x) bit for bit, without its branch
+            x = gelu_erf(x);                   // (straight-line code: common.hpp)
         }
         if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
         if (EPI == EPI_RESADD && DROP)
@@ -407,9 +407,8 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(gw[buf][j][e], ga[buf][j][e], c, 0, 0, 0);
                 if (EPI == EPI_GELU) {
-                    // GELU: ~32 VALU per value, 4 x the issue slots one MFMA leaves -- row group j of the parked sub-tile
-                    // is finished beside chunk pair j's 4 MFMAs (32 VALU behind each): the step takes about twice its
-                    // MFMA time, against a whole epilogue's ~2.8 steps when nothing overlaps
+                    // GELU: ~18 VALU per value, twice the issue slots one MFMA leaves -- row group j of the parked sub-tile
+                    // is finished beside chunk pair j's 4 MFMAs (~20 VALU behind each)
                     const int grow = pm0 + wr * 128 + mt * 32 + 8 * j + rrow, gcol = pn0 + wc * 64 + nt * 32 + c8 * 4;
                     f32x4 pre4, out4;
 #pragma unroll
@@ -425,7 +424,7 @@ __global__ __launch_bounds__(256) void gemm_f32p_kernel(const GemmArgs p) {
                     for (int i = 0; i < 4; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         if (j == 2 && t < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);
                     }
                 } else if (j == 2 && t < 7) {
 #pragma unroll
