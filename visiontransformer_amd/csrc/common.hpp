@@ -185,20 +185,21 @@ __device__ __forceinline__ float wave_max(float v) {
 // polynomials, an emulated expf, a select); erfc keeps the tail's RELATIVE precision and is one polynomial, one v_exp_f32
 // and a select: 18 instructions.  On the fp32 path every one of them is time added to the fp32 MFMAs.
 // Error against fp64 over ALL 2^32 inputs (tools/probes/gelu_check.hip): see DESIGN section 3; |error| <= 0.7e-6 of
-// max(|gelu|, 1e-2), median 0.4 ulp -- below the libm form's on both counts.  gelu(+inf) = +inf, NaN stays NaN.
+// max(|gelu|, 1e-2) -- the libm form: 8e-6.  gelu(+inf) = +inf, gelu(-huge) = -0, NaN stays NaN.
 __device__ __forceinline__ float gelu_erf(float u) {
 #pragma clang fp contract(off)   // every fused multiply-add is spelled out: all kernels must agree bit for bit
-    const float a = fminf(fabsf(u) * 0.70710678118654752440f, 5.0f);   // erfc(5) = 1.5e-12: nothing left of Phi beyond
-    float q = __uint_as_float(0xb6e5811du);
-    q = fmaf(a, q, __uint_as_float(0x38d55d79u));
-    q = fmaf(a, q, __uint_as_float(0xba2329bbu));
-    q = fmaf(a, q, __uint_as_float(0x3ae4efa2u));
-    q = fmaf(a, q, __uint_as_float(0x3a233c25u));
-    q = fmaf(a, q, __uint_as_float(0xbce796e6u));
-    q = fmaf(a, q, __uint_as_float(0x3e181a64u));
-    q = fmaf(a, q, __uint_as_float(0x3f6b1c07u));
-    q = fmaf(a, q, __uint_as_float(0x3fd05f5fu));
-    const float e = __builtin_amdgcn_exp2f(-(a * q));                  // erfc(a)
+    const float a = fabsf(u) * 0.70710678118654752440f;
+    const float c = fminf(a, 5.0f);   // the fit's range; beyond it Q stays at Q(5) = 7.86 and erfc decays as 2^(-7.86 a)
+    float q = __uint_as_float(0xb6e5811du);   // (erfc(5) = 1.5e-12: what is left of Phi there is below every fp32 ulp that matters)
+    q = fmaf(c, q, __uint_as_float(0x38d55d79u));
+    q = fmaf(c, q, __uint_as_float(0xba2329bbu));
+    q = fmaf(c, q, __uint_as_float(0x3ae4efa2u));
+    q = fmaf(c, q, __uint_as_float(0x3a233c25u));
+    q = fmaf(c, q, __uint_as_float(0xbce796e6u));
+    q = fmaf(c, q, __uint_as_float(0x3e181a64u));
+    q = fmaf(c, q, __uint_as_float(0x3f6b1c07u));
+    q = fmaf(c, q, __uint_as_float(0x3fd05f5fu));
+    const float e = __builtin_amdgcn_exp2f(-(a * q));                  // erfc(a); 0 once a q > 149
     const float w = u >= 0.f ? fmaf(e, -0.5f, 1.0f) : 0.5f * e;        // Phi(u); a NaN takes the second side and stays one
     return u * w;
 }
