@@ -107,7 +107,7 @@ int vitseg_version(void);
 const char* vitseg_last_error(void);
 /* Dispatcher switches for A/B measurements and tests (which kernel family takes a GEMM, precomputed dropout words on or
  * off, ...): process-wide, read by the launch path with one atomic load.  Names (case-insensitive): no_f32p, no_p8,
- * no_h16p, no_ragged_p8, no_dropmask, dropw_limit_mb, upsample_global, bf16_tiles, f32p_noinl, gn.  Each starts from the
+ * no_h16p, no_ragged_p8, no_dropmask, dropw_limit_mb, upsample_global, bf16_tiles, f32p_noinl, gn, no_mask2.  Each starts from the
  * environment variable VITSEG_<NAME> as it was when the library was loaded (the launch path itself never calls getenv).
  * The reference has no counterpart: its dispatch is ATen's. */
 int vitseg_set_option(const char* name, long long value);

@@ -178,6 +178,30 @@ def test_upsample_sigmoid_argmax_bit_exact(B, C, g, S):
     assert torch.equal(mask, mask2)
 
 
+@pytest.mark.parametrize("scale,delta,S,g", [(0.3, 1.0, 512, 32), (1.5, 1e-4, 512, 32), (6.0, 3e-3, 512, 32), (20.0, 1.0, 512, 32),
+                                             (0.3, 0.0, 512, 32), (3.0, 1e-6, 1024, 64), (1.0, 0.5, 256, 16)])
+def test_upsample_mask_only_two_classes(scale, delta, S, g):
+    """The two-class mask-only kernel (upsample_mask2_kernel: the sign of the interpolated class DIFFERENCE wherever it
+    clears the margin, the exact evaluation elsewhere) against the reference post-processing (bilinear -> sigmoid ->
+    first-max argmax, testViTModel.py:122-126) on EVERY pixel: well separated classes, differences at and below the
+    decision margins (every pixel ambiguous), exact ties (class 0 must win), logits beyond the range where any margin
+    settles the fp32 sigmoid comparison -- and against the general kernel."""
+    B = 3
+    z0 = _rand(B, 1, g, g, seed=S + g, scale=scale)
+    z = torch.cat([z0, z0 + delta * _rand(B, 1, g, g, seed=7)], dim=1).contiguous()
+    ref_mask = O.predict_mask(O.upsample_bilinear(z, (S, S)))
+    zd = z.to(DEV)
+    m_fast = torch.full((B, S, S), 7, dtype=torch.uint8, device=DEV)
+    _lib.check(_lib.lib().vitseg_op_upsample_argmax(zd.data_ptr(), None, m_fast.data_ptr(), B, 2, g, S, _stream()))
+    with _lib.option("no_mask2", 1):
+        m_gen = torch.full((B, S, S), 7, dtype=torch.uint8, device=DEV)
+        _lib.check(_lib.lib().vitseg_op_upsample_argmax(zd.data_ptr(), None, m_gen.data_ptr(), B, 2, g, S, _stream()))
+    assert torch.equal(m_fast.cpu().long(), ref_mask)
+    assert torch.equal(m_fast, m_gen)
+    if delta == 0.0:
+        assert int(m_fast.sum()) == 0
+
+
 # ---------------------------------------------------------------- 16-bit operand kernels (bf16 and IEEE half)
 FMT = {"bf16": (torch.bfloat16, 2 ** -8, "vitseg_op_linear_bf16", "vitseg_op_attention_bf16"),
        "fp16": (torch.float16, 2 ** -11, "vitseg_op_linear_f16", "vitseg_op_attention_f16")}

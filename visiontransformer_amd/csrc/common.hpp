@@ -32,6 +32,7 @@ enum Opt {
     OPT_BF16_TILES,        // round-1 16-bit tile choice: 0 by shape, 1 small (128x128), 2 large (256x128), 3 xl (256x256)
     OPT_F32P_NOINL,        // gemm_f32p: every epilogue at its tile's end
     OPT_GN,                // column-group width of the tile order (0: by shape)
+    OPT_NO_MASK2,          // two-class mask-only upsample through the general kernel instead of upsample_mask2_kernel
     OPT_COUNT
 };
 long opt(int id);

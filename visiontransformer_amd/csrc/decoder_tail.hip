@@ -236,6 +236,113 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     }
 }
 
+// Mask-only output for TWO classes (BASELINE configs[4]: 1 byte per pixel, no logits tensor): the same result as
+// upsample_kernel<true> on every pixel at a quarter of the arithmetic.  mask = 1 iff sigmoid(v1) > sigmoid(v0) (the first
+// maximal class wins ties), v_c = the ATen-exact bilinear value of class c.  Bilinear interpolation is linear, so
+// D = interp(z1 - z0) equals v1 - v0 up to fp32 rounding (|z| <= 8: < 6e-6 from a dozen roundings of values below 8).
+// Where |D| clears the margin that settles the sigmoid comparison (upsample_kernel's rule: 1e-4 while every |z| <= 2,
+// 4e-3 while <= 8; the block's low-res maximum bounds every interpolated value) plus that rounding slack, the sign of D
+// is the answer: ONE plain interpolation instead of two exact ones and the top-2 bookkeeping.  Every other pixel is
+// queued and resolved exactly as in upsample_kernel (ATen's fma placement, ATen's fp32 sigmoid, first maximum).
+__global__ __launch_bounds__(256) void upsample_mask2_kernel(const float* __restrict__ Z, uint8_t* __restrict__ mask, int B,
+                                                             int g, int S) {
+    extern __shared__ __attribute__((aligned(16))) float zs[];   // [z0 | z1 | z1 - z0][source row - ymin][g]
+    __shared__ unsigned amb_n, zmax_bits;
+    __shared__ unsigned amb_px[256 * UPR * 4];
+    const int quads = S >> 2, bands = S / UPR;
+    const float scale = (float)g / (float)S;
+    const int bpb = 256 / quads;
+    const size_t band0 = (size_t)blockIdx.x * bpb;
+    const int Yf = (int)(band0 % bands) * UPR, bimg = (int)(band0 / bands);
+    if (threadIdx.x == 0) {
+        amb_n = 0;
+        zmax_bits = 0;
+    }
+    int ya, yb, yc, yd;
+    float w0, w1;
+    taps(Yf, scale, g, ya, yb, w0, w1);
+    taps(Yf + bpb * UPR - 1, scale, g, yc, yd, w0, w1);
+    const int ymin = ya, nr = yd - ya + 1, per = nr * g;
+    __syncthreads();
+    if (bimg < B) {
+        unsigned mx = 0;
+        for (int i = threadIdx.x; i < per; i += 256) {
+            const float a = Z[((size_t)bimg * 2 + 0) * g * g + (size_t)ymin * g + i];
+            const float b = Z[((size_t)bimg * 2 + 1) * g * g + (size_t)ymin * g + i];
+            zs[i] = a;
+            zs[per + i] = b;
+            zs[2 * per + i] = b - a;
+            // |z| as an unsigned integer orders like the float; a NaN (exponent all ones, above every finite value) makes
+            // the whole block take the exact path
+            mx = max(mx, max(__float_as_uint(a) & 0x7fffffffu, __float_as_uint(b) & 0x7fffffffu));
+        }
+        atomicMax(&zmax_bits, mx);
+    }
+    __syncthreads();
+    const float zmax = __uint_as_float(zmax_bits);
+    // margin of upsample_kernel's rule + the rounding slack of D; no margin settles it once a logit may exceed 8
+    const float thr = zmax <= 2.0f ? 1.1e-4f : (zmax <= 8.0f ? 4.01e-3f : INFINITY);
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int xq = (int)(idx % quads);
+    const int Y0 = (int)((idx / quads) % bands) * UPR;
+    if (bimg < B) {
+        int x0[4], x1[4];
+        float wx0[4], wx1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) taps(4 * xq + e, scale, g, x0[e], x1[e], wx0[e], wx1[e]);
+        const float* zd = zs + 2 * per;
+        auto hrow = [&](int y) {
+            const float* z = zd + (y - ymin) * g;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(z[x0[e]], wx0[e], z[x1[e]] * wx1[e]);
+            return v;
+        };
+        int py0 = -1, py1 = -1;
+        f32x4 top = {0.f, 0.f, 0.f, 0.f}, bot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < UPR; ++r) {
+            int y0, y1;
+            float wy0, wy1;
+            taps(Y0 + r, scale, g, y0, y1, wy0, wy1);
+            if (y0 != py0) top = (y0 == py1) ? bot : hrow(y0);
+            if (y1 != py1) bot = hrow(y1);
+            py0 = y0;
+            py1 = y1;
+            uchar4 m4;
+            unsigned char cls[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = fmaf(top[e], wy0, bot[e] * wy1);
+                cls[e] = d > 0.f ? 1 : 0;
+                if (!(fabsf(d) >= thr))   // (a NaN difference is ambiguous too)
+                    amb_px[atomicAdd(&amb_n, 1u)] = (unsigned)(((Y0 + r - Yf) << 12) | (4 * xq + e));
+            }
+            m4.x = cls[0]; m4.y = cls[1]; m4.z = cls[2]; m4.w = cls[3];
+            *(uchar4*)(mask + ((size_t)bimg * S + Y0 + r) * S + 4 * xq) = m4;
+        }
+    }
+    __syncthreads();   // the queue is complete and this block's provisional bytes are written
+    const unsigned n_amb = amb_n;
+    for (unsigned i = threadIdx.x; i < n_amb; i += 256) {
+        const int Y = Yf + (int)(amb_px[i] >> 12), X = (int)(amb_px[i] & 0xfffu);
+        int y0, y1, xa, xb;
+        float wya, wyb, wxa, wxb;
+        taps(Y, scale, g, y0, y1, wya, wyb);
+        taps(X, scale, g, xa, xb, wxa, wxb);
+        float sg[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {   // the fma placement of upsample_kernel, then ATen's fp32 sigmoid
+            const float* zt = zs + c * per + (y0 - ymin) * g;
+            const float* zb = zs + c * per + (y1 - ymin) * g;
+            const float top = __fmaf_rn(zt[xa], wxa, __fmul_rn(zt[xb], wxb));
+            const float bot = __fmaf_rn(zb[xa], wxa, __fmul_rn(zb[xb], wxb));
+            sg[c] = sigmoid_aten(__fmaf_rn(top, wya, __fmul_rn(bot, wyb)));
+        }
+        mask[((size_t)bimg * S + Y) * S + X] = sg[1] > sg[0] ? 1 : 0;
+    }
+}
+
 // nn.CrossEntropyLoss() on the upsampled logits (model/CE/classes.py:268,280): mean over B*S*S pixels of
 // logsumexp_c(logit) - logit[target].  The logits are re-generated from the low-res map (same exact
 // bilinear arithmetic as upsample_kernel) instead of being read back from HBM, so the loss costs one
@@ -349,6 +456,13 @@ int launch_upsample(const float* Z, float* logits, uint8_t* mask, int B, int C, 
     const int rows_out = whole ? (256 / quads) * UPR : 0;
     const size_t nr_max = (size_t)((double)rows_out * g / S) + 3;
     const size_t smem = (size_t)C * nr_max * g * sizeof(float);
+    if (whole && C == 2 && !logits && 3 * nr_max * g * sizeof(float) <= 32 * 1024 && !opt(OPT_UPSAMPLE_GLOBAL) &&
+        !opt(OPT_NO_MASK2)) {   // mask-only, two classes: the class difference decides (upsample_mask2_kernel)
+        hipLaunchKernelGGL(upsample_mask2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 3 * nr_max * g * sizeof(float), s,
+                           Z, mask, B, g, S);
+        VITSEG_LAUNCH_CHECK("upsample_mask2");
+        return VITSEG_OK;
+    }
     if (whole && smem <= 48 * 1024 && !opt(OPT_UPSAMPLE_GLOBAL))
         hipLaunchKernelGGL(upsample_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), smem, s, Z, logits, mask, B,
                            C, g, S);

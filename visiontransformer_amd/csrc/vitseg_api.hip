@@ -33,7 +33,7 @@ int hip_fail(hipError_t e, const char* what) {
 
 // ---- dispatcher switches (common.hpp Opt) ----
 static const char* const g_opt_names[OPT_COUNT] = {"no_f32p", "no_p8", "no_h16p", "no_ragged_p8", "no_dropmask",
-                                                   "dropw_limit_mb", "upsample_global", "bf16_tiles", "f32p_noinl", "gn"};
+                                                   "dropw_limit_mb", "upsample_global", "bf16_tiles", "f32p_noinl", "gn", "no_mask2"};
 static std::atomic<long> g_opts[OPT_COUNT];
 static int opt_index(const char* name) {
     if (!name) return -1;
