@@ -73,6 +73,10 @@ int main(int argc, char** argv) {
         // P8_WHERE_LDA=64: the activation rows overlap (row stride 128 B): an 8 MB operand that stays in the L2 / Infinity
         // Cache instead of 100-400 MB streamed from HBM -- same instruction stream, shorter load latency
         if (getenv("P8_WHERE_LDA")) a.lda = atoi(getenv("P8_WHERE_LDA"));
+        static unsigned long long* clk = nullptr;   // "clock" variants of p8_where.sh: per-block (shader ticks, 100 MHz ticks)
+        if (!clk) { hipMalloc(&clk, 4096 * 16); }
+        hipMemset(clk, 0, 4096 * 16);
+        a.thin_scratch = (float*)clk;
         float best = 1e9f;
         for (int rnd = 0; rnd < 4; ++rnd) {
             hipEventRecord(e0, 0);
@@ -86,8 +90,21 @@ int main(int argc, char** argv) {
         }
         // per 64-deep K step of a 256 x 256 tile, one tile per CU and round (256 CUs): what the main loop costs
         const double ksteps = (double)((M + 255) / 256) * (s.N / 256) / 256.0 * (s.K / 64);
-        printf("%-30s %8.1f us  %7.1f TFLOP/s  %6.3f us per K step (%.0f steps)\n", s.name, best * 1e3,
+        printf("%-30s %8.1f us  %7.1f TFLOP/s  %6.3f us per K step (%.0f steps)", s.name, best * 1e3,
                2.0 * M * s.N * s.K / (best * 1e-3) * 1e-12, best * 1e3 / ksteps, ksteps);
+        {   // in-kernel clock, if this build stamps it: median over the blocks of the last launch
+            static unsigned long long h[512];
+            hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+            double r[256];
+            int n = 0;
+            for (int b = 0; b < 256; ++b)
+                if (h[2 * b + 1]) r[n++] = (double)h[2 * b] / (double)h[2 * b + 1] * 0.1;   // GHz
+            if (n) {
+                for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (r[j] < r[i]) { double t = r[i]; r[i] = r[j]; r[j] = t; }
+                printf("  clock %.2f GHz (median of %d blocks; %.0f cycles per K step)", r[n / 2], n, best * 1e3 / ksteps * r[n / 2] * 1e3);
+            }
+        }
+        printf("\n");
     }
     }
     {   // weight gradient (TT form): dW[768][3072] over 65536 tokens

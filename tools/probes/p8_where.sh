@@ -51,10 +51,21 @@ noread = rep(noepi, "        for (int mt = 0; mt < 4; ++mt)\n#pragma unroll\n   
 noread = rep(noread, "        for (int nt = 0; nt < 2; ++nt)\n#pragma unroll\n            for (int ks = 0; ks < 2; ++ks) {\n                if (TT)\n                    w[nt][ks]",
              "        for (int nt = 0; nt < (p.M < 0 ? 2 : 0); ++nt)\n#pragma unroll\n            for (int ks = 0; ks < 2; ++ks) {\n                if (TT)\n                    w[nt][ks]")
 w("noepi_noread", noread)
+# in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): shader-clock ticks (s_memtime) over 100 MHz ticks
+# (s_memrealtime) around the whole kernel of wave 0 of every block, written to GemmArgs::thin_scratch (unused by this kernel)
+def clocked(t):
+    t = rep(t, "    const int tid = threadIdx.x, lane = tid & 63;\n    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);\n    const int wr = wave >> 2, wc = wave & 3;",
+            "    const int tid = threadIdx.x, lane = tid & 63;\n    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);\n    const int wr = wave >> 2, wc = wave & 3;\n    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();")
+    t = rep(t, "    if (wr == 0) P8_BAR();\n    P8_VMCNT(0);\n#undef P8_KSTEP",
+            "    if (wr == 0) P8_BAR();\n    P8_VMCNT(0);\n    if (tid == 0 && p.thin_scratch) {\n        ((unsigned long long*)p.thin_scratch)[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;\n        ((unsigned long long*)p.thin_scratch)[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;\n    }\n#undef P8_KSTEP")
+    return t
+w("clock", clocked(s))
+w("noepi_clock", clocked(noepi))
 nobar = rep(noepi, "        __builtin_amdgcn_s_barrier();         \\\n", "        ;         \\\n")
 w("noepi_nobarrier", nobar)
 nodma = rep(noepi, '"s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds"', '""')
 w("noepi_nodma", nodma)
+w("noepi_nodma_clock", clocked(nodma))
 PY
 for v in ${P8_WHERE_VARIANTS:-base noepi nostore epi_nolds noepi_nobarrier noepi_nodma}; do
   p8src=$v; hsrc=h16p
