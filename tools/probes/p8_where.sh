@@ -59,6 +59,11 @@ def clocked(t):
     t = rep(t, "    if (wr == 0) P8_BAR();\n    P8_VMCNT(0);\n#undef P8_KSTEP",
             "    if (wr == 0) P8_BAR();\n    P8_VMCNT(0);\n    if (tid == 0 && p.thin_scratch) {\n        ((unsigned long long*)p.thin_scratch)[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;\n        ((unsigned long long*)p.thin_scratch)[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;\n    }\n#undef P8_KSTEP")
     return t
+# de-phasing experiment: half of the CUs (odd XCD-local index) start ~DELAY us late, so that their epilogues (store bursts,
+# VALU) fall into the other half's main loops
+for delay_us in (4, 8, 16):
+    w("stagger%d" % delay_us, rep(s, "    // ---- prologue: fill the stream (halves 0 .. 5 of the block's sequence), first B0 fragments ----",
+      "    if (((blockIdx.x >> 3) & 1) && !TT) { const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); while (__builtin_amdgcn_s_memrealtime() - t0 < %dull) __builtin_amdgcn_s_sleep(8); }\n    // ---- prologue: fill the stream (halves 0 .. 5 of the block's sequence), first B0 fragments ----" % (delay_us * 100)))
 w("clock", clocked(s))
 w("noepi_clock", clocked(noepi))
 nobar = rep(noepi, "        __builtin_amdgcn_s_barrier();         \\\n", "        ;         \\\n")
