@@ -211,12 +211,34 @@ __device__ __forceinline__ float gelu_erf_grad(float u) {
     return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
 }
 
-// GELU and its derivative for tensors that are rounded to 16 bits right away (bf16 2^-9, IEEE half 2^-12 relative): the erfc
-// form of gelu_erf above with a degree-5 Q fitted on [0, 4.5] (tools/fit_gelu_erfc.py: fit(4.5, 5, 1e-5, 1e-2)): |error| <=
-// 1.9e-6 of max(|gelu|, 1e-2) and 6.8e-7 absolute in gelu' -- two orders below the rounding of the result -- at 15 vector
-// instructions for Phi, 1 more for gelu, 6 more for gelu' (rounds 1-3: Abramowitz-Stegun 7.1.28, 27 for the pair; the
-// epilogue of fc1 is VALU-bound at two waves per SIMD: DESIGN section 3).
-__device__ __forceinline__ float gelu16_phi(float u) {   // Phi(u) = (1 + erf(u / sqrt 2)) / 2
+// GELU alone for tensors that are rounded to 16 bits right away (inference): erf by Abramowitz-Stegun 7.1.28,
+// erf x = 1 - (1 + a1 x + ... + a6 x^6)^-16, |abs error| <= 3e-7 -- three orders below the rounding of the result -- at 15
+// plain vector instructions.  (The erfc form below needs 16 for GELU alone and measured 5 % slower in fc1's epilogue,
+// 358-363 vs 343-345 us at B = 64; it wins when the derivative is wanted too.)
+__device__ __forceinline__ float gelu_erf_fast(float u) {
+    const float x = fabsf(u) * 0.70710678118654752440f;
+    float t = fmaf(x, 0.0000430638f, 0.0002765672f);
+    t = fmaf(x, t, 0.0001520143f);
+    t = fmaf(x, t, 0.0092705272f);
+    t = fmaf(x, t, 0.0422820123f);
+    t = fmaf(x, t, 0.0705230784f);
+    t = fmaf(x, t, 1.0f);
+    t = t * t;
+    t = t * t;
+    t = t * t;
+    t = t * t;
+    const float erf_abs = 1.0f - __builtin_amdgcn_rcpf(t);  // t -> inf gives erf = 1
+    return 0.5f * u + 0.5f * fabsf(u) * erf_abs;              // u * Phi(u), erf odd
+}
+// GELU AND its derivative (training: fc1's epilogue saves gelu'(u) for the backward), both rounded to 16 bits right away:
+// the erfc form of gelu_erf above with a degree-5 Q fitted on [0, 4.5] (tools/fit_gelu_erfc.py: fit(4.5, 5, 1e-5, 1e-2)):
+// |error| <= 1.9e-6 of max(|gelu|, 1e-2) and 6.8e-7 absolute in gelu' -- two orders below the rounding of the results.
+// Phi is shared: 22 vector instructions for the pair against 27 with two Abramowitz-Stegun evaluations (rounds 1-3);
+// fc1 + GELU + saved derivative at B = 64 on one box: 413-420 vs 434-436 us (the epilogue is VALU-bound).
+struct GeluPair {
+    float g, d;   // gelu(u), gelu'(u)
+};
+__device__ __forceinline__ GeluPair gelu_erf_pair_fast(float u) {
     const float a = fabsf(u) * 0.70710678118654752440f;
     const float c = fminf(a, 4.5f);
     float q = __uint_as_float(0xb98ef51du);
@@ -225,15 +247,11 @@ __device__ __forceinline__ float gelu16_phi(float u) {   // Phi(u) = (1 + erf(u 
     q = fmaf(c, q, __uint_as_float(0x3e1a8172u));
     q = fmaf(c, q, __uint_as_float(0x3f6af0d8u));
     q = fmaf(c, q, __uint_as_float(0x3fd0616eu));
-    const float e = __builtin_amdgcn_exp2f(-(a * q));   // erfc(a)
-    return u >= 0.f ? fmaf(e, -0.5f, 1.0f) : 0.5f * e;
+    const float e = __builtin_amdgcn_exp2f(-(a * q));                      // erfc(a)
+    const float phi = u >= 0.f ? fmaf(e, -0.5f, 1.0f) : 0.5f * e;          // Phi(u) = (1 + erf(u / sqrt 2)) / 2
+    const float pdf = __builtin_amdgcn_exp2f((u * u) * -0.72134752044448170368f);   // exp(-u^2 / 2)
+    return GeluPair{u * phi, fmaf(u * pdf, 0.39894228040143267794f, phi)};   // u Phi(u), Phi(u) + u phi(u)
 }
-// d/du [u Phi(u)] = Phi(u) + u phi(u), phi(u) = exp(-u^2 / 2) / sqrt(2 pi)
-__device__ __forceinline__ float gelu_erf_grad_fast(float u) {
-    const float ph = __builtin_amdgcn_exp2f((u * u) * -0.72134752044448170368f);
-    return fmaf(u * ph, 0.39894228040143267794f, gelu16_phi(u));
-}
-__device__ __forceinline__ float gelu_erf_fast(float u) { return u * gelu16_phi(u); }
 
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     // round-to-nearest-even; NaN stays NaN (quiet)

@@ -503,8 +503,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float (*lds)[2][BM 
                     float x = v[ps][e] + bias4[e];
                     // saved for the backward: fp32 keeps the pre-activation u, the 16-bit path keeps gelu'(u) itself
                     // (the backward epilogue is then one multiply instead of an erf + exp per element)
-                    if (EPI == EPI_GELU && p.aux) aux4[e] = sizeof(T) == 4 ? x : gelu_erf_grad_fast(x);
-                    if (EPI == EPI_GELU) x = (sizeof(T) == 4) ? gelu_erf(x) : gelu_erf_fast(x);
+                    if (EPI == EPI_GELU) {
+                        if (sizeof(T) == 4) {
+                            if (p.aux) aux4[e] = x;
+                            x = gelu_erf(x);
+                        } else if (p.aux) {
+                            { const GeluPair gp = gelu_erf_pair_fast(x); x = gp.g; aux4[e] = gp.d; }
+                        } else {
+                            x = gelu_erf_fast(x);
+                        }
+                    }
                     if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
                     if (EPI == EPI_RESADD && p.drop.thresh)
                         x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow + p.row_base), gcol + e, p.drop.thresh)
@@ -630,8 +638,10 @@ __global__ __launch_bounds__(256) void thin_reduce_kernel(const float* __restric
     for (int e = 0; e < 4; ++e) {
         float x = acc[e] + b4[e];
         if (EPI == EPI_GELU) {
-            if (sizeof(OutT) != 4 && aux) der[e] = gelu_erf_grad_fast(x);
-            x = sizeof(OutT) == 4 ? gelu_erf(x) : gelu_erf_fast(x);  // as the tile kernels of that format
+            // as the tile kernels of that format
+            if (sizeof(OutT) == 4) x = gelu_erf(x);
+            else if (aux) { const GeluPair gp = gelu_erf_pair_fast(x); x = gp.g; der[e] = gp.d; }
+            else x = gelu_erf_fast(x);
         }
         if (EPI == EPI_RESADD) {
             if (drop.thresh) x = drop_keep(key, (unsigned)(c + e), drop.thresh) ? x * drop.scale : 0.f;
@@ -1070,8 +1080,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_large_kernel(const GemmArgs p) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = v[ps][e] + bias4[e];
-                    if (EPI == EPI_GELU && p.aux) pre[e] = gelu_erf_grad_fast(x);   // saved for the backward: gelu'(u)
-                    if (EPI == EPI_GELU) x = gelu_erf_fast(x);
+                    if (EPI == EPI_GELU) {
+                        if (p.aux) { const GeluPair gp = gelu_erf_pair_fast(x); x = gp.g; pre[e] = gp.d; }   // pre: gelu'(u), saved for the backward
+                        else x = gelu_erf_fast(x);
+                    }
                     if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
                     if (EPI == EPI_RESADD && p.drop.thresh)
                         x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow + p.row_base), gcol + e, p.drop.thresh)

@@ -391,8 +391,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) {
                     float x = v[i][e] + bias_r[e];
-                    if (EPI == EPI_GELU && p.aux) pre[e] = gelu_erf_grad_fast(x);   // saved for the backward: gelu'(u)
-                    if (EPI == EPI_GELU) x = gelu_erf_fast(x);
+                    if (EPI == EPI_GELU) {
+                        if (p.aux) { const GeluPair gp = gelu_erf_pair_fast(x); x = gp.g; pre[e] = gp.d; }   // pre: gelu'(u), saved for the backward
+                        else x = gelu_erf_fast(x);
+                    }
                     if (EPI == EPI_RESADD && p.drop.thresh)
                         x = drop_keep(drop_key(p.drop.seed, p.drop.stream, grow + p.row_base), gcol + e, p.drop.thresh)
                                 ? x * p.drop.scale : 0.f;
