@@ -42,7 +42,6 @@ __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 
 // MW (with DROP, without RAGGED): the keep bits come as precomputed words (common.hpp attn_dropmask_words): the lane mask
 // of accumulator register r is one scalar 64-bit load, applied with one v_cndmask; the 1 / (1 - p) factor moves into the
 // final normalisation.
-constexpr float DEFER_THR = 8.0f;
 template <bool DROP, bool RAGGED, bool MW, typename H>
 __global__ __launch_bounds__(256, 3) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ lse, int B, int Np, int A,
