@@ -67,8 +67,8 @@ KERNEL_NAMES = {  # precision -> kind -> kernel symbol as rocprofv3 prints it
                    "train_dgrad": "gemm_p8_kernel<unsigned short, *, {0,5}, 0> + gemm_h16p_kernel<unsigned short> (o_proj) + transpose_bf16_kernel (activation gradients)",
                    "train_wgrad": "gemm_p8_kernel<unsigned short, float, 0, 1> + splitk_reduce_kernel (weight gradients)",
                    "train_attn_fwd": "attn_dropmask_kernel + attn_bf16_kernel<true, false, true, unsigned short> + attn_cls_bf16_kernel<unsigned short>",
-                   "train_attn_bwd": "attn_bwd_dkv_bf16_kernel<true, false, true> + attn_bwd_dq_bf16_kernel<true, false, true> + "
-                                     "attn_bwd_cls_bf16_kernel<true> + attn_delta_bf16_kernel"},
+                   "train_attn_bwd": "attn_bwd_dq_bf16_kernel<true, false, true> (also forms delta) + attn_bwd_dkv_bf16_kernel<true, false, true> + "
+                                     "attn_bwd_cls_finish_kernel<true>"},
     "train_f32": {"train_gemm_fwd": "gemm_f32p_kernel<{0,1,2}, ...> (the four forward linears)", "train_dgrad": "gemm_kernel<float, float, ...> (W T-form)",
                   "train_wgrad": "gemm_kernel<float, float, ...> (both T-form, split-K)",
                   "train_attn_fwd": "attn_f32_kernel<true>",

@@ -300,11 +300,14 @@ int vitseg_op_gemm_f32(const float* A, const float* W, const float* R, float* C,
 int vitseg_op_attention_bwd_f32(const float* qkv, const float* dctx, float* ctx_out, float* lse_out, float* scratch,
                                 float* dqkv, int batch, int num_patches, int num_heads, void* stream);
 /* bf16 attention core forward + backward (dropout_p > 0: the counter-based mask of csrc/common.hpp on the attention
- * probabilities, stream id = layer * 8 + 1); ctx_out bf16 [Mt, D], lse_out / scratch fp32 [B, A, Np + 1], dqkv bf16 [Mt, 3D].
+ * probabilities, stream id = layer * 8 + 1); ctx_out bf16 [Mt, D], lse_out fp32 [B, A, Np + 1], dqkv bf16 [Mt, 3D].
  * dropmask_words (optional, vitseg_attention_dropmask_bytes; needs num_patches % 128 == 0 and dropout_p > 0): the keep
  * bits are generated once into this buffer and read by the three kernels -- the path vitseg_forward_train /
- * vitseg_backward take -- instead of being hashed per element in each of them; the masks are the same bits. */
+ * vitseg_backward take -- instead of being hashed per element in each of them; the masks are the same bits.
+ * scratch: vitseg_attention_bwd_scratch_floats() floats (delta [B, A, Np + 1] + the per-block partial sums of the CLS
+ * token's own gradients). */
 size_t vitseg_attention_dropmask_bytes(int batch, int num_patches, int num_heads);
+size_t vitseg_attention_bwd_scratch_floats(int batch, int num_patches, int num_heads);
 int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_out, float* lse_out, float* scratch,
                                  void* dqkv, int batch, int num_patches, int num_heads, float dropout_p,
                                  uint32_t dropout_seed, uint32_t dropout_stream, void* dropmask_words, void* stream);

@@ -649,7 +649,7 @@ def test_attention_backward_bf16(B, Np, A, p):
     qd, dd = qkv.to(DEV), dctx.to(DEV)
     ctx = torch.zeros(Mt, D, device=DEV, dtype=torch.bfloat16)
     lse = torch.empty(B * A * N, device=DEV)
-    scr = torch.empty(B * A * N, device=DEV)
+    scr = torch.empty(_lib.lib().vitseg_attention_bwd_scratch_floats(B, Np, A), device=DEV)
     dqkv = torch.full((Mt, 3 * D), float("nan"), device=DEV, dtype=torch.bfloat16)
     mw = torch.empty(_lib.lib().vitseg_attention_dropmask_bytes(B, Np, A), dtype=torch.uint8, device=DEV) if words else None
     _lib.check(_lib.lib().vitseg_op_attention_bwd_bf16(qd.data_ptr(), dd.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
@@ -692,7 +692,7 @@ def test_attention_backward_bf16_is_its_rounding_model(Np, A, spread, p):
     qd, dd = qkv.to(DEV), dctx.to(DEV)
     ctx = torch.zeros(Mt, D, device=DEV, dtype=torch.bfloat16)
     lse = torch.empty(B * A * N, device=DEV)
-    scr = torch.empty(B * A * N, device=DEV)
+    scr = torch.empty(_lib.lib().vitseg_attention_bwd_scratch_floats(B, Np, A), device=DEV)
     dqkv = torch.full((Mt, 3 * D), float("nan"), device=DEV, dtype=torch.bfloat16)
     mw = torch.empty(_lib.lib().vitseg_attention_dropmask_bytes(B, Np, A), dtype=torch.uint8, device=DEV) if words else None
     _lib.check(_lib.lib().vitseg_op_attention_bwd_bf16(qd.data_ptr(), dd.data_ptr(), ctx.data_ptr(), lse.data_ptr(),

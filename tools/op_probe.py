@@ -39,7 +39,7 @@ if a.op == "attn_bwd":   # bf16 attention forward (with lse) + backward, optiona
     dctx = torch.randn(Mt, D, device=dev).to(torch.bfloat16)
     ctx = torch.empty(Mt, D, device=dev, dtype=torch.bfloat16)
     lse = torch.empty(a.B * a.A * (a.Np + 1), device=dev)
-    scr = torch.empty_like(lse)
+    scr = torch.empty(L.vitseg_attention_bwd_scratch_floats(a.B, a.Np, a.A), device=dev)
     dqkv = torch.empty(Mt, 3 * D, device=dev, dtype=torch.bfloat16)
     mw = torch.empty(L.vitseg_attention_dropmask_bytes(a.B, a.Np, a.A), dtype=torch.uint8, device=dev) if a.words else None
     run = lambda: _lib.check(L.vitseg_op_attention_bwd_bf16(qkv.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), lse.data_ptr(),

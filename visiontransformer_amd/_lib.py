@@ -33,7 +33,7 @@ EXPORTS = [
     "vitseg_resize_taps", "vitseg_resize_coeffs", "vitseg_nearest_index", "vitseg_preprocess_u8",
     "vitseg_resize_nearest_u8", "vitseg_eval_counts", "vitseg_paed_scratch_bytes", "vitseg_paed_multiclass_loss",
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32", "vitseg_op_linear_h16_ex",
-    "vitseg_op_wgrad_bf16", "vitseg_op_wgrad_bf16_scratch_floats", "vitseg_op_attention_bwd_bf16", "vitseg_attention_dropmask_bytes", "vitseg_op_colsum_scratch_floats",
+    "vitseg_op_wgrad_bf16", "vitseg_op_wgrad_bf16_scratch_floats", "vitseg_op_attention_bwd_bf16", "vitseg_attention_dropmask_bytes", "vitseg_attention_bwd_scratch_floats", "vitseg_op_colsum_scratch_floats",
     "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss", "vitseg_op_linear_f32_ex", "vitseg_resize_nearest_i64",
 ]
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
@@ -120,6 +120,8 @@ def lib() -> C.CDLL:
         l.vitseg_adam_step.argtypes = [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, f32, vp]
         l.vitseg_op_gemm_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+        l.vitseg_attention_bwd_scratch_floats.argtypes = [i32, i32, i32]
+        l.vitseg_attention_bwd_scratch_floats.restype = sz
         l.vitseg_op_attention_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
         l.vitseg_attention_dropmask_bytes.argtypes = [i32, i32, i32]
         l.vitseg_attention_dropmask_bytes.restype = C.c_size_t

@@ -12,7 +12,13 @@
 //                 dS^T registers are directly the B operand of dQ^T += K^T dS^T; the CLS key is one vector update.
 //   attn_bwd_dkv: a block owns 128 patch keys and loops over the patch-query tiles (a KEY on each lane; P / dS
 //                 registers are the B operands of dV^T += dO^T P~ and dK^T += Q^T dS); the CLS query is one vector update.
-//   attn_bwd_cls: dq of the CLS query and dk / dv of the CLS key (two reductions over all tokens) per (image, head).
+//   the CLS token's own gradients -- dq of the CLS query (a sum over all keys), dk / dv of the CLS key (sums over all
+//   queries) -- leave the two kernels above as per-block partial vectors (round 4: the dQ kernel has p, dS of every one of
+//   its queries against the CLS key, the dK/dV kernel those of the CLS query against every one of its keys; a side
+//   kernel used to stream q | k | v | dO of every token a third time, 403 MB per layer at B = 64) and attn_bwd_cls_finish
+//   adds them up in block order with the CLS-CLS pair's term.  delta_i = sum_d dO_id O_id is formed by the dQ kernel in its
+//   prologue (it holds dO_i anyway; the dK/dV kernel, launched behind it, reads the values it wrote) instead of a pass of
+//   its own over ctx and dctx.
 // The row constants enter as the INITIAL accumulators of the S and dP chains (-lse / c, -delta), so the inner element
 // work is  p = exp2(c s'),  ds = p dp'  -- no subtraction, no running maximum -- and the loop bodies are branch-free
 // (dropout and raggedness are template parameters): hipcc can then overlap one tile's MFMAs with the other's VALU.
@@ -31,39 +37,6 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-
-// delta[b][h][n] = sum_d dO * O.  A thread owns 8 consecutive channels of a token row (one 16-byte load of each
-// tensor), the 8 lanes of a head combine with three lane swaps; consecutive threads walk a row, so a wave reads 1 KiB
-// contiguous.
-__global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const bf16_t* __restrict__ ctx,
-                                                              const bf16_t* __restrict__ dctx,
-                                                              float* __restrict__ delta, int B, int Np, int A) {
-    const int N = Np + 1, cpr = A * 8;                     // 16-byte chunks per row
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)(B * N) * cpr;
-    float v = 0.f;
-    size_t row = 0;
-    int h = 0;
-    if (i < total) {
-        row = i / cpr;
-        const int c = (int)(i - row * cpr);
-        h = c >> 3;
-        const uint4 o = *(const uint4*)(ctx + row * (size_t)(A * HD) + c * 8);
-        const uint4 d = *(const uint4*)(dctx + row * (size_t)(A * HD) + c * 8);
-        v = bf_lo(o.x) * bf_lo(d.x) + bf_hi(o.x) * bf_hi(d.x) + bf_lo(o.y) * bf_lo(d.y) + bf_hi(o.y) * bf_hi(d.y) +
-            bf_lo(o.z) * bf_lo(d.z) + bf_hi(o.z) * bf_hi(d.z) + bf_lo(o.w) * bf_lo(d.w) + bf_hi(o.w) * bf_hi(d.w);
-    }
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    if (i < total && (threadIdx.x & 7) == 0) {
-        // row index in the patches-first layout -> (image, token) with the CLS token last
-        const size_t BNp = (size_t)B * Np;
-        const int bimg = row < BNp ? (int)(row / Np) : (int)(row - BNp);
-        const int n = row < BNp ? (int)(row - (size_t)bimg * Np) : Np;
-        delta[((size_t)bimg * A + h) * N + n] = v;
-    }
-}
 
 // One [64 tokens][64 d] bf16 tile serves BOTH kinds of read: rows of 128 B, 16-byte chunk c of row r stored at
 // c ^ f(r), f = the 3 bits of r >> 1 rotated right by one.  f is a bijection of (r >> 1) & 7, so the 16 rows of a
@@ -130,14 +103,63 @@ __device__ __forceinline__ float dot_frag(const f32x4 (&a)[4], const f32x4 (&b)[
     return part + __shfl_xor(part, 32, 64);
 }
 
+// Sum over the block's 128 tokens of per-token vectors: lane (li, lh) holds NV vectors' 32 channels {16 s + 8 lh + j} of ITS
+// token (x[v][4 s + (j >> 1)] as produced below).  Quad sums by DPP, the 8 quad sums of a wave and the 4 waves through
+// `red` (>= NV * 32 * 64 floats of LDS, free once the tile loop is over), 64 NV threads finish in a fixed order and write
+// out[v * 64 + channel].  All 256 threads call it.
+template <int NV>
+__device__ __forceinline__ void block_channel_sums(float (&x)[NV][32], float* red, float* out, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            float t = x[v][e];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            x[v][e] = t;
+        }
+    __syncthreads();   // every wave is done with the tiles
+    if ((li & 3) == 0) {
+        const int row = wave * 8 + (li >> 2);   // 32 rows of quad sums
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                // x[v][e]: e = 8 s + j -> channel 16 s + 8 lh + j
+                const int ch = 16 * (e >> 3) + 8 * lh + (e & 7);
+                red[(v * 32 + row) * 64 + ch] = x[v][e];
+            }
+    }
+    __syncthreads();
+    if (tid < NV * 64) {
+        const int v = tid >> 6, ch = tid & 63;
+        float t = 0.f;
+        for (int r = 0; r < 32; ++r) t += red[(v * 32 + r) * 64 + ch];
+        out[v * 64 + ch] = t;
+    }
+}
+// the 8 bf16 values of fragment register group s of a lane, as floats: e = 8 s + j <-> channel 16 s + 8 lh + j
+__device__ __forceinline__ void frag_floats(const f32x4 (&f)[4], float (&o)[32]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned u = __float_as_uint(f[s][e]);
+            o[8 * s + 2 * e] = bf_lo(u);
+            o[8 * s + 2 * e + 1] = bf_hi(u);
+        }
+}
+
 // ---------------------------------------------------------------------------------- dQ (patch queries)
 // MW (both MFMA kernels; with DROP, without RAGGED): keep bits from the precomputed words (common.hpp
 // attn_dropmask_words) instead of one hash per element.
 template <bool DROP, bool RAGGED, bool MW>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
+                                                                  const bf16_t* __restrict__ ctx,
                                                                   const bf16_t* __restrict__ dctx,
                                                                   const float* __restrict__ lse,
-                                                                  const float* __restrict__ delta,
+                                                                  float* __restrict__ delta, float* __restrict__ clsp,
                                                                   bf16_t* __restrict__ dqkv, int B, int Np, int A,
                                                                   DropArgs dr, const unsigned* __restrict__ maskw) {
     static_assert(!MW || (DROP && !RAGGED), "mask words: dropout on, whole 128-token blocks");
@@ -162,7 +184,22 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
         dof[s] = *(const f32x4*)(dctx + q_row * (size_t)D + head * HD + 16 * s + 8 * lh);
     }
     const size_t stat = ((size_t)b * A + head) * N + (q_valid ? nq : Np - 1);
-    const float lse_q = lse[stat], ndelta = -delta[stat];
+    // delta of this lane's query = dO . O over the 64 channels (the bf16 context the forward wrote); published for the dK/dV
+    // kernel, which is launched behind this one
+    float dl_q;
+    {
+        f32x4 of[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) of[s] = *(const f32x4*)(ctx + q_row * (size_t)D + head * HD + 16 * s + 8 * lh);
+        dl_q = dot_frag(dof, of);
+        if (q_valid && lh == 0) delta[stat] = dl_q;
+        if (at.rt == 0 && wave == 0) {   // ... and the CLS query's (wave-uniform branch): one channel per lane
+            const float x = bf16_to_f32(dctx[cls_row * (size_t)D + head * HD + lane]) * bf16_to_f32(ctx[cls_row * (size_t)D + head * HD + lane]);
+            const float t = wave_sum(x);
+            if (lane == 0) delta[((size_t)b * A + head) * N + Np] = t;
+        }
+    }
+    const float lse_q = lse[stat], ndelta = -dl_q;
     const float nlse = -lse_q * (1.0f / c);     // initial accumulator of the S chain: p = exp2(c (q.k - lse / c))
     const unsigned dkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + nq));  // same mask as forward
 
@@ -286,6 +323,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
     }
     if (MW) lm.wait();   // the last iteration's mask load is still writing its 64 SGPRs: nothing may reuse them before it lands
     // ---- the CLS key: one vector update per query (ds is a scalar per lane) ----
+    float cls_ds, cls_pm;
     {
         f32x4 kc[4], vc[4];
 #pragma unroll
@@ -308,6 +346,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
                 dq[dt][4 * g4 + 2] = fmaf(ds, bf_lo(t.y), dq[dt][4 * g4 + 2]);
                 dq[dt][4 * g4 + 3] = fmaf(ds, bf_hi(t.y), dq[dt][4 * g4 + 3]);
             }
+        cls_ds = ds;
+        cls_pm = p * m;
     }
     if (q_valid) {
         bf16_t* out = dqkv + q_row * ld + head * HD;
@@ -321,6 +361,27 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
                 *(uint2*)(out + dt * 32 + 8 * g4 + 4 * lh) = t;
             }
     }
+    // (behind the stores: the 32 accumulator registers are free by now)
+    {
+    // ---- this block's share of the CLS KEY's gradients: dk_cls += ds q, dv_cls += p~ dO over its (valid) queries ----
+    // (one vector at a time: 32 registers; partial record of block rt = [dq_cls | dk_cls | dv_cls][64])
+    float* rec = clsp + (((size_t)b * A + head) * ((Np + TB - 1) / TB) + at.rt) * 192;
+    const float dsv = q_valid ? cls_ds : 0.f, pmv = q_valid ? cls_pm : 0.f;
+    {
+        float x[1][32];
+        frag_floats(qf, x[0]);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) x[0][e] *= dsv;
+        block_channel_sums<1>(x, (float*)&lds[0][0][0], rec + 64, tid);
+    }
+    {
+        float x[1][32];
+        frag_floats(dof, x[0]);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) x[0][e] *= pmv;
+        block_channel_sums<1>(x, (float*)&lds[0][0][0], rec + 128, tid);
+    }
+    }
 }
 
 // ---------------------------------------------------------------------------------- dK, dV (patch keys)
@@ -329,6 +390,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                                                                    const bf16_t* __restrict__ dctx,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ delta,
+                                                                   float* __restrict__ clsp,
                                                                    bf16_t* __restrict__ dqkv, int B, int Np, int A,
                                                                    DropArgs dr, const unsigned* __restrict__ maskw) {
     static_assert(!MW || (DROP && !RAGGED), "mask words: dropout on, whole 128-token blocks");
@@ -527,6 +589,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
         __syncthreads();
     }
     // ---- the CLS query: one vector update per key (p and ds are scalars per lane) ----
+    float cls_ds;
     {
         f32x4 qc[4], oc[4];
 #pragma unroll
@@ -554,6 +617,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                 dv[dt][4 * g4 + 2] = fmaf(pm, bf_lo(to.y), dv[dt][4 * g4 + 2]);
                 dv[dt][4 * g4 + 3] = fmaf(pm, bf_hi(to.y), dv[dt][4 * g4 + 3]);
             }
+        cls_ds = ds;
     }
     if (k_valid) {
         bf16_t* outk = dqkv + k_row * ld + D + head * HD;
@@ -571,127 +635,94 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                 *(uint2*)(outv + dt * 32 + 8 * g4 + 4 * lh) = tv;
             }
     }
+    // (behind the stores: the 64 accumulator registers are free by now)
+    // ---- this block's share of the CLS QUERY's gradient: dq_cls += ds k over its (valid) keys ----
+    {
+        const float dsv = k_valid ? cls_ds : 0.f;
+        float x[1][32];
+        frag_floats(kf, x[0]);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) x[0][e] *= dsv;
+        block_channel_sums<1>(x, (float*)&lds[0][0][0], clsp + (((size_t)b * A + head) * ((Np + TB - 1) / TB) + at.rt) * 192, tid);
+    }
 }
 
 // ---------------------------------------------------------------------------------- the CLS token
-// dq of the CLS query (sum over all N keys) and dk, dv of the CLS key (sums over all N queries) of one (head, image):
-// 8 lanes share a token row (16 bytes each: whole 128-byte lines), 32 tokens per pass, fp32 vector arithmetic.
+// dq of the CLS query, dk / dv of the CLS key of one (head, image): the per-block partial vectors of the two kernels above,
+// summed in block order, plus the CLS-CLS pair's term.  One wave per (head, image), lane = channel.
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_cls_bf16_kernel(const bf16_t* __restrict__ qkv,
-                                                                const bf16_t* __restrict__ dctx,
-                                                                const float* __restrict__ lse,
-                                                                const float* __restrict__ delta,
-                                                                bf16_t* __restrict__ dqkv, int B, int Np, int A,
-                                                                DropArgs dr) {
-    __shared__ float red[3][32][HD];
-    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
-    const int head = blockIdx.x, b = blockIdx.y;
-    const int D = A * HD, ld = 3 * D, N = Np + 1;
-    const size_t row0 = (size_t)b * Np, cls_row = (size_t)B * Np + b;
-    const size_t stat0 = ((size_t)b * A + head) * N;
+__global__ __launch_bounds__(64) void attn_bwd_cls_finish_kernel(const bf16_t* __restrict__ qkv,
+                                                                 const bf16_t* __restrict__ dctx,
+                                                                 const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta,
+                                                                 const float* __restrict__ clsp,
+                                                                 bf16_t* __restrict__ dqkv, int B, int Np, int A,
+                                                                 DropArgs dr) {
+    const int d = threadIdx.x, head = blockIdx.x, b = blockIdx.y;
+    const int D = A * HD, ld = 3 * D, N = Np + 1, nrt = (Np + TB - 1) / TB;
+    const size_t cls_row = (size_t)B * Np + b, stat_c = ((size_t)b * A + head) * N + Np;
     const float c = 0.125f * LOG2E;
-    auto load8 = [&](const bf16_t* ptr, float (&out)[8]) {
-        const uint4 u = *(const uint4*)ptr;
-        out[0] = bf_lo(u.x); out[1] = bf_hi(u.x); out[2] = bf_lo(u.y); out[3] = bf_hi(u.y);
-        out[4] = bf_lo(u.z); out[5] = bf_hi(u.z); out[6] = bf_lo(u.w); out[7] = bf_hi(u.w);
-    };
-    auto dot8 = [&](const float (&x)[8], const float (&y)[8]) {
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf(x[e], y[e], s);
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        return s;
-    };
-    float qc[8], kc[8], vc[8], oc[8];
-    load8(qkv + cls_row * ld + head * HD + 8 * sub, qc);
-    load8(qkv + cls_row * ld + D + head * HD + 8 * sub, kc);
-    load8(qkv + cls_row * ld + 2 * D + head * HD + 8 * sub, vc);
-    load8(dctx + cls_row * (size_t)D + head * HD + 8 * sub, oc);
-    const float lse_c = lse[stat0 + Np], delta_c = delta[stat0 + Np];
-    const unsigned key_c = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + Np));
-    float aq[8], ak[8], av[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) aq[e] = ak[e] = av[e] = 0.f;
-    for (int n0 = 0; n0 < N; n0 += 32) {
-        const int n = n0 + grp;
-        const bool ok = n < N;
-        const size_t row = !ok ? cls_row : (n < Np ? row0 + n : cls_row);
-        float qn[8], kn[8], vn[8], on[8];
-        load8(qkv + row * ld + head * HD + 8 * sub, qn);
-        load8(qkv + row * ld + D + head * HD + 8 * sub, kn);
-        load8(qkv + row * ld + 2 * D + head * HD + 8 * sub, vn);
-        load8(dctx + row * (size_t)D + head * HD + 8 * sub, on);
-        // token n as a KEY of the CLS query
-        const float s1 = dot8(qc, kn), d1 = dot8(oc, vn);
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(s1, c, -lse_c));
-        float m1 = 1.f;
-        if (DROP) m1 = drop_keep(key_c, (unsigned)n, dr.thresh) ? dr.scale : 0.f;
-        const float ds1 = ok ? p1 * fmaf(d1, m1, -delta_c) : 0.f;
-        // token n as a QUERY of the CLS key
-        const size_t sn = stat0 + (ok ? n : Np);
-        const float s2 = dot8(qn, kc), d2 = dot8(on, vc);
-        const float p2 = __builtin_amdgcn_exp2f(fmaf(s2, c, -lse[sn]));
-        float m2 = 1.f;
-        if (DROP) m2 = drop_keep(drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + n)), (unsigned)Np, dr.thresh) ? dr.scale : 0.f;
-        const float pm2 = ok ? p2 * m2 : 0.f;
-        const float ds2 = ok ? p2 * fmaf(d2, m2, -delta[sn]) : 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            aq[e] = fmaf(ds1, kn[e], aq[e]);
-            ak[e] = fmaf(ds2, qn[e], ak[e]);
-            av[e] = fmaf(pm2, on[e], av[e]);
-        }
+    float aq = 0.f, ak = 0.f, av = 0.f;
+    const float* rec = clsp + ((size_t)b * A + head) * nrt * 192;
+    for (int rt = 0; rt < nrt; ++rt) {   // fixed order: deterministic
+        aq += rec[rt * 192 + d];
+        ak += rec[rt * 192 + 64 + d];
+        av += rec[rt * 192 + 128 + d];
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        red[0][grp][8 * sub + e] = aq[e];
-        red[1][grp][8 * sub + e] = ak[e];
-        red[2][grp][8 * sub + e] = av[e];
-    }
-    __syncthreads();
-    if (tid < 3 * HD) {
-        const int which = tid / HD, d = tid - which * HD;
-        float s = 0.f;
-        for (int g = 0; g < 32; ++g) s += red[which][g][d];   // fixed order: deterministic
-        if (which < 2) s *= 0.125f;
-        dqkv[cls_row * ld + which * D + head * HD + d] = f32_to_bf16(s);
-    }
+    const float qc = bf16_to_f32(qkv[cls_row * ld + head * HD + d]);
+    const float kc = bf16_to_f32(qkv[cls_row * ld + D + head * HD + d]);
+    const float vc = bf16_to_f32(qkv[cls_row * ld + 2 * D + head * HD + d]);
+    const float oc = bf16_to_f32(dctx[cls_row * (size_t)D + head * HD + d]);
+    const float s = wave_sum(qc * kc), dp = wave_sum(oc * vc);
+    const float p = __builtin_amdgcn_exp2f(fmaf(s, c, -lse[stat_c]));
+    float m = 1.f;
+    if (DROP) m = drop_keep(drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + Np)), (unsigned)Np, dr.thresh) ? dr.scale : 0.f;
+    const float ds = p * fmaf(dp, m, -delta[stat_c]);
+    aq = fmaf(ds, kc, aq);
+    ak = fmaf(ds, qc, ak);
+    av = fmaf(p * m, oc, av);
+    dqkv[cls_row * ld + head * HD + d] = f32_to_bf16(aq * 0.125f);
+    dqkv[cls_row * ld + D + head * HD + d] = f32_to_bf16(ak * 0.125f);
+    dqkv[cls_row * ld + 2 * D + head * HD + d] = f32_to_bf16(av);
 }
 
 template <bool DROP>
-int launch_bwd(const bf16_t* qkv, const bf16_t* dctx, const float* lse, const float* dvec, bf16_t* dqkv, int B, int Np,
-               int A, DropArgs dr, hipStream_t s, const unsigned* maskw) {
+int launch_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* lse, float* dvec, bf16_t* dqkv, int B,
+               int Np, int A, DropArgs dr, hipStream_t s, const unsigned* maskw) {
     const dim3 grid((unsigned)((Np + TB - 1) / TB) * A * B);  // 1-D: attn_tile() places the tiles
+    float* clsp = dvec + (size_t)B * A * (Np + 1);            // per-block CLS partials behind the delta vector
 #define VITSEG_BWD(RG, MWORDS)                                                                                         \
     do {                                                                                                               \
-        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DROP, RG, MWORDS>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec,   \
-                           dqkv, B, Np, A, dr, maskw);                                                                 \
+        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DROP, RG, MWORDS>), grid, dim3(256), 0, s, qkv, ctx, dctx, lse,    \
+                           dvec, clsp, dqkv, B, Np, A, dr, maskw);                                                     \
         VITSEG_LAUNCH_CHECK("attn_bwd_dq_bf16");                                                                       \
         hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DROP, RG, MWORDS>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec,  \
-                           dqkv, B, Np, A, dr, maskw);                                                                 \
+                           clsp, dqkv, B, Np, A, dr, maskw);                                                           \
         VITSEG_LAUNCH_CHECK("attn_bwd_dkv_bf16");                                                                      \
     } while (0)
     if (Np % TB != 0) VITSEG_BWD(true, false);
     else if (DROP && maskw) VITSEG_BWD(false, DROP);
     else VITSEG_BWD(false, false);
 #undef VITSEG_BWD
-    hipLaunchKernelGGL(attn_bwd_cls_bf16_kernel<DROP>, dim3(A, B), dim3(256), 0, s, qkv, dctx, lse, dvec, dqkv, B, Np, A, dr);
-    VITSEG_LAUNCH_CHECK("attn_bwd_cls_bf16");
+    hipLaunchKernelGGL(attn_bwd_cls_finish_kernel<DROP>, dim3(A, B), dim3(64), 0, s, qkv, dctx, lse, dvec, clsp, dqkv, B, Np,
+                       A, dr);
+    VITSEG_LAUNCH_CHECK("attn_bwd_cls_finish");
     return VITSEG_OK;
 }
 
 }  // namespace
 
+// floats of launch_attention_bwd_bf16's scratch: delta [B, A, Np + 1] + one [dq_cls | dk_cls | dv_cls][64] record per
+// 128-token block of every (image, head)
+size_t attention_bwd_bf16_scratch_floats(int B, int Np, int A) {
+    return (size_t)B * A * ((size_t)(Np + 1) + (size_t)((Np + TB - 1) / TB) * 192);
+}
+
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dvec,
                               void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s, const unsigned* maskw) {
     VITSEG_CHECK_ARG(qkv && ctx && dctx && lse && dvec && dqkv, VITSEG_EINVAL, "attention_bwd_bf16: null pointer");
-    hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3((unsigned)(((size_t)B * (Np + 1) * A * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ctx,
-                       (const bf16_t*)dctx, dvec, B, Np, A);
-    VITSEG_LAUNCH_CHECK("attn_delta_bf16");
-    return dr.thresh ? launch_bwd<true>((const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s, maskw)
-                     : launch_bwd<false>((const bf16_t*)qkv, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s, nullptr);
+    return dr.thresh ? launch_bwd<true>((const bf16_t*)qkv, (const bf16_t*)ctx, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s, maskw)
+                     : launch_bwd<false>((const bf16_t*)qkv, (const bf16_t*)ctx, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s, nullptr);
 }
 
 }  // namespace vitseg

@@ -489,6 +489,10 @@ size_t vitseg_attention_dropmask_bytes(int batch, int num_patches, int num_heads
                ? attn_dropmask_words(batch, num_patches, num_heads) * sizeof(unsigned) : 0;
 }
 
+size_t vitseg_attention_bwd_scratch_floats(int batch, int num_patches, int num_heads) {
+    return batch > 0 && num_heads > 0 && num_patches > 0 ? attention_bwd_bf16_scratch_floats(batch, num_patches, num_heads) : 0;
+}
+
 int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_out, float* lse_out, float* scratch,
                                  void* dqkv, int batch, int num_patches, int num_heads, float dropout_p,
                                  uint32_t dropout_seed, uint32_t dropout_stream, void* dropmask_words, void* stream) {
