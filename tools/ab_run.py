@@ -14,6 +14,23 @@ import visiontransformer_amd._lib as L  # noqa: E402
 
 if sys.argv[1] == "prev":
     L.LIB_PATH = L.LIB_PATH.replace("libvitseg.so", "libvitseg_prev.so")
+    import ctypes
+    _old = ctypes.CDLL(L.LIB_PATH)          # an older build may lack the newest entry points: check only what it has
+    L.EXPORTS = [n for n in L.EXPORTS if hasattr(_old, n)]
+
+    class _Missing:                         # stands in for an entry point the old build does not have (argtypes are set on it)
+        argtypes = restype = None
+
+    class _Lenient(ctypes.CDLL):
+        def __getattr__(self, name):
+            try:
+                return super().__getattr__(name)
+            except AttributeError:
+                if name.startswith("vitseg_"):
+                    return _Missing()
+                raise
+
+    ctypes.CDLL = _Lenient
 rest = sys.argv[2:]
 if rest and rest[0] == "bench":
     script, rest = os.path.join(ROOT, "bench.py"), rest[1:]

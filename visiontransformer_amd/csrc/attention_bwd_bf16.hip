@@ -103,52 +103,47 @@ __device__ __forceinline__ float dot_frag(const f32x4 (&a)[4], const f32x4 (&b)[
     return part + __shfl_xor(part, 32, 64);
 }
 
-// Sum over the block's 128 tokens of per-token vectors: lane (li, lh) holds NV vectors' 32 channels {16 s + 8 lh + j} of ITS
-// token (x[v][4 s + (j >> 1)] as produced below).  Quad sums by DPP, the 8 quad sums of a wave and the 4 waves through
-// `red` (>= NV * 32 * 64 floats of LDS, free once the tile loop is over), 64 NV threads finish in a fixed order and write
-// out[v * 64 + channel].  All 256 threads call it.
-template <int NV>
-__device__ __forceinline__ void block_channel_sums(float (&x)[NV][32], float* red, float* out, int tid) {
+// Sum over the block's 128 tokens of per-token vectors.  Lane (li, lh) holds 32 channels {16 s + 8 lh + j} of ITS token's
+// vector as scale * (the bf16 fragment registers f).  Quad sums by DPP (2 steps), the 32 quad sums of the block (8 per
+// wave) as rows of `red` (32 x 64 floats per vector, in the tile buffers, which are free once the loop is over), 64
+// threads per vector add the rows in a fixed order.  stage: every lane, after a block barrier that ends the tile loop;
+// finish: after the barrier that follows the last stage.
+__device__ __forceinline__ void cls_stage(const f32x4 (&f)[4], float scale, float* red, int tid) {
     const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    float* row = red + (wave * 8 + (li >> 2)) * 64 + 8 * lh;
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            float t = x[v][e];
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            x[v][e] = t;
-        }
-    __syncthreads();   // every wave is done with the tiles
-    if ((li & 3) == 0) {
-        const int row = wave * 8 + (li >> 2);   // 32 rows of quad sums
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-#pragma unroll
-            for (int e = 0; e < 32; ++e) {
-                // x[v][e]: e = 8 s + j -> channel 16 s + 8 lh + j
-                const int ch = 16 * (e >> 3) + 8 * lh + (e & 7);
-                red[(v * 32 + row) * 64 + ch] = x[v][e];
-            }
-    }
-    __syncthreads();
-    if (tid < NV * 64) {
-        const int v = tid >> 6, ch = tid & 63;
-        float t = 0.f;
-        for (int r = 0; r < 32; ++r) t += red[(v * 32 + r) * 64 + ch];
-        out[v * 64 + ch] = t;
-    }
-}
-// the 8 bf16 values of fragment register group s of a lane, as floats: e = 8 s + j <-> channel 16 s + 8 lh + j
-__device__ __forceinline__ void frag_floats(const f32x4 (&f)[4], float (&o)[32]) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s) {
+        float t[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const unsigned u = __float_as_uint(f[s][e]);
-            o[8 * s + 2 * e] = bf_lo(u);
-            o[8 * s + 2 * e + 1] = bf_hi(u);
+            t[2 * e] = bf_lo(u) * scale;
+            t[2 * e + 1] = bf_hi(u) * scale;
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            t[j] += __shfl_xor(t[j], 1, 64);
+            t[j] += __shfl_xor(t[j], 2, 64);
+        }
+        if ((li & 3) == 0) {   // channels 16 s + 8 lh + 0..7: two 16-byte stores
+            *(f32x4*)(row + 16 * s) = f32x4{t[0], t[1], t[2], t[3]};
+            *(f32x4*)(row + 16 * s + 4) = f32x4{t[4], t[5], t[6], t[7]};
+        }
+    }
+}
+__device__ __forceinline__ void cls_finish(const float* red, float* out, int nv, int tid) {
+    if (tid < nv * 64) {
+        const float* col = red + (tid >> 6) * 2048 + (tid & 63);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four chains: the 32 reads are in flight together
+#pragma unroll
+        for (int r = 0; r < 32; r += 4) {
+            a0 += col[r * 64];
+            a1 += col[(r + 1) * 64];
+            a2 += col[(r + 2) * 64];
+            a3 += col[(r + 3) * 64];
+        }
+        out[tid] = (a0 + a1) + (a2 + a3);
+    }
 }
 
 // ---------------------------------------------------------------------------------- dQ (patch queries)
@@ -363,24 +358,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
     }
     // (behind the stores: the 32 accumulator registers are free by now)
     {
-    // ---- this block's share of the CLS KEY's gradients: dk_cls += ds q, dv_cls += p~ dO over its (valid) queries ----
-    // (one vector at a time: 32 registers; partial record of block rt = [dq_cls | dk_cls | dv_cls][64])
-    float* rec = clsp + (((size_t)b * A + head) * ((Np + TB - 1) / TB) + at.rt) * 192;
-    const float dsv = q_valid ? cls_ds : 0.f, pmv = q_valid ? cls_pm : 0.f;
-    {
-        float x[1][32];
-        frag_floats(qf, x[0]);
-#pragma unroll
-        for (int e = 0; e < 32; ++e) x[0][e] *= dsv;
-        block_channel_sums<1>(x, (float*)&lds[0][0][0], rec + 64, tid);
-    }
-    {
-        float x[1][32];
-        frag_floats(dof, x[0]);
-#pragma unroll
-        for (int e = 0; e < 32; ++e) x[0][e] *= pmv;
-        block_channel_sums<1>(x, (float*)&lds[0][0][0], rec + 128, tid);
-    }
+    // ---- this block's share of the CLS KEY's gradients: dk_cls += ds q, dv_cls += p~ dO over its (valid) queries;
+    // partial record of block rt = [dq_cls | dk_cls | dv_cls][64] ----
+        float* rec = clsp + (((size_t)b * A + head) * ((Np + TB - 1) / TB) + at.rt) * 192;
+        float* red = (float*)&lds[0][0][0];
+        __syncthreads();   // every wave is done with the tiles
+        cls_stage(qf, q_valid ? cls_ds : 0.f, red, tid);
+        cls_stage(dof, q_valid ? cls_pm : 0.f, red + 2048, tid);
+        __syncthreads();
+        cls_finish(red, rec + 64, 2, tid);
     }
 }
 
@@ -638,12 +624,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
     // (behind the stores: the 64 accumulator registers are free by now)
     // ---- this block's share of the CLS QUERY's gradient: dq_cls += ds k over its (valid) keys ----
     {
-        const float dsv = k_valid ? cls_ds : 0.f;
-        float x[1][32];
-        frag_floats(kf, x[0]);
-#pragma unroll
-        for (int e = 0; e < 32; ++e) x[0][e] *= dsv;
-        block_channel_sums<1>(x, (float*)&lds[0][0][0], clsp + (((size_t)b * A + head) * ((Np + TB - 1) / TB) + at.rt) * 192, tid);
+        float* red = (float*)&lds[0][0][0];
+        __syncthreads();   // every wave is done with the tiles
+        cls_stage(kf, k_valid ? cls_ds : 0.f, red, tid);
+        __syncthreads();
+        cls_finish(red, clsp + (((size_t)b * A + head) * ((Np + TB - 1) / TB) + at.rt) * 192, 1, tid);
     }
 }
 
