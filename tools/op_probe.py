@@ -26,6 +26,7 @@ ap.add_argument("--A", type=int, default=12)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--drop", type=float, default=0.0)
+ap.add_argument("--scale", type=float, default=1.0, help="attention: standard deviation of the q | k | v entries")
 ap.add_argument("--aux", action="store_true", help="linear_ex, epi 1: also write the saved GELU derivative")
 ap.add_argument("--words", action="store_true", help="attn_bwd: dropout keep bits as precomputed mask words")
 a = ap.parse_args()
@@ -77,7 +78,7 @@ elif a.op == "linear" and a.bf16:
     work = 2.0 * a.M * a.N * a.K
 elif a.op == "attention" and a.bf16:
     D = 64 * a.A
-    qkv = torch.randn(a.B * a.Np + a.B, 3 * D, device=dev).to(torch.bfloat16)
+    qkv = (torch.randn(a.B * a.Np + a.B, 3 * D, device=dev) * a.scale).to(torch.bfloat16)
     ctx = torch.empty(a.B * a.Np + a.B, D, device=dev, dtype=torch.bfloat16)
     run = lambda: _lib.check(L.vitseg_op_attention_bf16(qkv.data_ptr(), ctx.data_ptr(), a.B, a.Np, a.A, st))
     work = 4.0 * a.B * a.A * (a.Np + 1) ** 2 * 64
