@@ -64,6 +64,12 @@ def clocked(t):
 for delay_us in (4, 8, 16):
     w("stagger%d" % delay_us, rep(s, "    // ---- prologue: fill the stream (halves 0 .. 5 of the block's sequence), first B0 fragments ----",
       "    if (((blockIdx.x >> 3) & 1) && !TT) { const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); while (__builtin_amdgcn_s_memrealtime() - t0 < %dull) __builtin_amdgcn_s_sleep(8); }\n    // ---- prologue: fill the stream (halves 0 .. 5 of the block's sequence), first B0 fragments ----" % (delay_us * 100)))
+# epilogue without its two explicit LDS waits per m tile (LDS operations of one wave execute in order)
+nowaits = rep(s, """            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private: no barrier needed
+""", "")
+nowaits = rep(nowaits, """            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab is free for the next m tile
+""", "")
+w("nowaits", nowaits)
 w("clock", clocked(s))
 w("noepi_clock", clocked(noepi))
 nobar = rep(noepi, "        __builtin_amdgcn_s_barrier();         \\\n", "        ;         \\\n")
