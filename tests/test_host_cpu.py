@@ -130,3 +130,27 @@ def test_dropout_generator_statistics():
     r = (m.rows(0, 3, (2, 256, 192)).numpy() > 0).astype(np.float64)
     assert abs(r.mean() - 0.9) < 3e-3 and abs(corr(r[..., :-1], r[..., 1:])) < 0.01
     assert abs(r.mean(axis=(0, 1)).std()) < 0.02            # no column that is dropped (or kept) systematically
+
+
+def test_dispatcher_options_table():
+    """vitseg_set_option / vitseg_get_option (include/vitseg.h): names are case-insensitive, unknown names are an error with a
+    message, `_lib.option` restores the previous value, and the launch path's switches start from the environment once."""
+    import subprocess
+    import sys
+    for name in ("no_f32p", "no_p8", "no_h16p", "no_ragged_p8", "no_dropmask", "upsample_global", "f32p_noinl", "gn", "no_mask2"):
+        assert _lib.get_option(name) == 0, name
+    assert _lib.get_option("dropw_limit_mb") == -1 and _lib.get_option("bf16_tiles") == 0
+    with _lib.option("NO_P8", 1):
+        assert _lib.get_option("no_p8") == 1
+        with _lib.option("gn", 8):
+            assert _lib.get_option("GN") == 8
+        assert _lib.get_option("gn") == 0
+    assert _lib.get_option("no_p8") == 0
+    with pytest.raises(RuntimeError, match="unknown option"):
+        _lib.set_option("no_such_switch", 1)
+    # initial values come from VITSEG_<NAME> as the library is loaded (a fresh process)
+    code = ("from visiontransformer_amd import _lib; "
+            "print(_lib.get_option('no_h16p'), _lib.get_option('bf16_tiles'), _lib.get_option('dropw_limit_mb'))")
+    env = dict(os.environ, VITSEG_NO_H16P="1", VITSEG_BF16_TILES="large", VITSEG_DROPW_LIMIT_MB="64")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["1", "2", "64"], out
