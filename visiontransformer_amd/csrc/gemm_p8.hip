@@ -168,9 +168,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
         c.w[2] = left <= 0 ? 0 : (left >= capW ? 0x7fffffff : left * p.ldw * 2 - c.n0 * 2);
     };
     auto add_base = [](i32x4& r, unsigned bytes) {
-        const unsigned lo = (unsigned)r[0] + bytes;
-        r[1] += lo < bytes ? 1 : 0;
-        r[0] = (int)lo;
+        int lo = r[0], hi = r[1];      // (hipcc turns the C carry idiom into five scalar instructions; these are the two)
+        asm("s_add_u32 %0, %0, %2\n\ts_addc_u32 %1, %1, 0" : "+s"(lo), "+s"(hi) : "s"(bytes) : "scc");
+        r[0] = lo;
+        r[1] = hi;
     };
     auto set_tile = [&](Cursor& c) {
         if (c.ts < my_tiles) {
@@ -206,9 +207,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
             ++c.ts;
             set_tile(c);
         } else if (TT) {
+            // next 64 token rows of the same item: the bases move on, the bytes left to the end of the matrix shrink by the
+            // same amount (never saturated: wgrad_p8_applies keeps K * ld * 2 below 2^31), 0 once the step lies beyond the
+            // last row -- 5 scalar instructions per operand instead of set_records_tt's multiplies and selects
             add_base(c.a, stepA);
             add_base(c.w, stepW);
-            set_records_tt(c);
+            c.a[2] = max(c.a[2] - (int)stepA, 0);
+            c.w[2] = max(c.w[2] - (int)stepW, 0);
         }
     };
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
