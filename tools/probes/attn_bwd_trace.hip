@@ -35,7 +35,8 @@ int main() {
     unsigned short *qkv, *ctx, *dctx, *dqkv;
     float *lse, *dvec;
     hipMalloc(&qkv, rows * 3 * D * 2); hipMalloc(&ctx, rows * D * 2); hipMalloc(&dctx, rows * D * 2); hipMalloc(&dqkv, rows * 3 * D * 2);
-    hipMalloc(&lse, (size_t)B * A * (Np + 1) * 4); hipMalloc(&dvec, (size_t)B * A * (Np + 1) * 4);
+    hipMalloc(&lse, (size_t)B * A * (Np + 1) * 4);
+    hipMalloc(&dvec, vitseg::attention_bwd_bf16_scratch_floats(B, Np, A) * 4);   // delta + the per-block CLS partials
     fill16<<<2048, 256>>>(qkv, rows * 3 * D, 1u, 1.5f);
     fill16<<<2048, 256>>>(ctx, rows * D, 2u, 1.f);
     fill16<<<2048, 256>>>(dctx, rows * D, 3u, 1.f);

@@ -112,6 +112,10 @@ int main(int argc, char** argv) {
         a.A = A; a.W = R16; a.C = C; a.M = 768; a.N = 3072; a.K = M; a.lda = 768; a.ldw = 3072; a.ldc = 3072;
         float* scratch;
         hipMalloc(&scratch, (size_t)768 * 3072 * 4 * 16);
+        static unsigned long long* clk2 = nullptr;
+        if (!clk2) hipMalloc(&clk2, 4096 * 16);
+        hipMemset(clk2, 0, 4096 * 16);
+        a.thin_scratch = (float*)clk2;
         float best = 1e9f;
         for (int rnd = 0; rnd < 4; ++rnd) {
             hipEventRecord(e0, 0);
@@ -123,7 +127,24 @@ int main(int argc, char** argv) {
             hipEventElapsedTime(&ms, e0, e1);
             if (rnd && ms / 10 < best) best = ms / 10;
         }
-        printf("%-30s %8.1f us  %7.1f TFLOP/s\n", "wgrad fc1 (TT, split-K)", best * 1e3, 2.0 * M * 768 * 3072 / (best * 1e-3) * 1e-12);
+        const int splits = vitseg::wgrad_p8_splits(768, 3072, M);
+        const double ksteps = (double)((M + 63) / 64) / splits;   // one item per CU: 64-token steps of a slice
+        printf("%-30s %8.1f us  %7.1f TFLOP/s  %6.3f us per K step (%.0f steps, reduce kernel included)", "wgrad fc1 (TT, split-K)", best * 1e3,
+               2.0 * M * 768 * 3072 / (best * 1e-3) * 1e-12, best * 1e3 / ksteps, ksteps);
+        {
+            static unsigned long long h[512];
+            hipMemcpy(h, clk2, sizeof(h), hipMemcpyDeviceToHost);
+            double r[256], cyc[256];
+            int n = 0;
+            for (int b = 0; b < 256; ++b)
+                if (h[2 * b + 1]) { r[n] = (double)h[2 * b] / (double)h[2 * b + 1] * 0.1; cyc[n++] = (double)h[2 * b]; }
+            if (n) {
+                for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (r[j] < r[i]) { double t = r[i]; r[i] = r[j]; r[j] = t; }
+                for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (cyc[j] < cyc[i]) { double t = cyc[i]; cyc[i] = cyc[j]; cyc[j] = t; }
+                printf("  clock %.2f GHz (median of %d blocks; %.0f shader cycles per K step, kernel only)", r[n / 2], n, cyc[n / 2] / ksteps);
+            }
+        }
+        printf("\n");
     }
     return 0;
 }

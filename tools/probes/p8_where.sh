@@ -2,9 +2,9 @@
 # builds tools/probes/p8_where.hip against the product kernel and against patched copies (gpurun_out/p8_where/) and prints
 # one timing block per variant.  Run on the GPU box:  bash tools/probes/p8_where.sh     (P8_WHERE_VARIANTS="base noepi")
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
-out=gpurun_out/p8_where
+out=${P8_WHERE_OUT:-gpurun_out/p8_where}   # P8_WHERE_OUT=tools/probes/_build/p8 P8_WHERE_BUILD_ONLY=1 here, then P8_WHERE_RUN_ONLY=1 on the box
 mkdir -p $out
-python3 - visiontransformer_amd/csrc/gemm_p8.hip "$out" <<'PY'
+[ -z "$P8_WHERE_RUN_ONLY" ] && python3 - visiontransformer_amd/csrc/gemm_p8.hip "$out" <<'PY'
 import os, sys
 src, out = sys.argv[1], sys.argv[2]
 s = open(src).read().replace('#include "kernels.hpp"', '#include "%s/visiontransformer_amd/csrc/kernels.hpp"' % os.getcwd())
@@ -77,10 +77,21 @@ w("noepi_nobarrier", nobar)
 nodma = rep(noepi, '"s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds"', '""')
 w("noepi_nodma", nodma)
 w("noepi_nodma_clock", clocked(nodma))
+w("noepi_noread_clock", clocked(noread))
+w("noepi_noread_nodma_clock", clocked(rep(noread, '"s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds"', '""')))
+w("noepi_nobarrier_clock", clocked(nobar))
+# the cursors never move (every K step streams the same rows): the scalar work of advance() is gone
+noadv = rep(noepi, "        advance(cur0);                                                                               \\\n        advance(cur1);                                                                               \\\n", "")
+w("noepi_noadvance_clock", clocked(noadv))
+# wave priorities: (a) none at all, (b) the fragment reads + DMA issue of a phase above the other wave row's MFMAs
+noprio = rep(rep(s, "        __builtin_amdgcn_s_setprio(1);\n", ""), "        __builtin_amdgcn_s_setprio(0);\n", "")
+w("noprio_clock", clocked(noprio))
+readprio = rep(rep(s, "        __builtin_amdgcn_s_setprio(1);\n", "        __builtin_amdgcn_s_setprio(0);\n"), "        __builtin_amdgcn_s_setprio(0);\n    };", "        __builtin_amdgcn_s_setprio(1);\n    };")
+w("readprio_clock", clocked(readprio))
 PY
 for v in ${P8_WHERE_VARIANTS:-base noepi nostore epi_nolds noepi_nobarrier noepi_nodma}; do
   p8src=$v; hsrc=h16p
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DP8_SRC="\"$PWD/$out/$p8src.hip\"" -DH16P_SRC="\"$PWD/$out/$hsrc.hip\"" tools/probes/p8_where.hip -o $out/$v 2> $out/$v.err || { cat $out/$v.err; exit 1; }
+  [ -z "$P8_WHERE_RUN_ONLY" ] && { hipcc --offload-arch=gfx950 -O3 -std=c++17 -DP8_SRC="\"$PWD/$out/$p8src.hip\"" -DH16P_SRC="\"$PWD/$out/$hsrc.hip\"" tools/probes/p8_where.hip -o $out/$v 2> $out/$v.err || { cat $out/$v.err; exit 1; }; }
   echo "== $v"
   if [ -z "$P8_WHERE_BUILD_ONLY" ]; then $out/$v $P8_WHERE_M || exit 1; fi
 done
