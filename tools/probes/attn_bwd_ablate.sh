@@ -11,7 +11,14 @@ for v in $variants; do
 python3 - visiontransformer_amd/csrc/attention_bwd_bf16.hip "$out" "$v" <<'PY' || exit 1
 import os, sys
 src, out, v = sys.argv[1], sys.argv[2], sys.argv[3]
-s = open(src).read().replace('#include "kernels.hpp"', '#include "%s/visiontransformer_amd/csrc/kernels.hpp"' % os.getcwd())
+if v.startswith("old"):    # the committed kernels (git HEAD), for a same-box A/B against the working tree
+    import subprocess
+    text = subprocess.check_output(["git", "show", "HEAD:" + src]).decode()
+    v_apply = "base"
+else:
+    text = open(src).read()
+    v_apply = v
+s = text.replace('#include "kernels.hpp"', '#include "%s/visiontransformer_amd/csrc/kernels.hpp"' % os.getcwd())
 def rep(t, a, b, cnt=-1):
     assert t.count(a) >= 1, a
     return t.replace(a, b) if cnt < 0 else t.replace(a, b, cnt)
@@ -22,31 +29,31 @@ i = s.index("// ----------------------------------------------------------------
 j = s.index("// ---------------------------------------------------------------------------------- dK, dV (patch keys)")
 k = s.index("// ---------------------------------------------------------------------------------- the CLS token")
 head, dq, dkv, tail = s[:i], s[i:j], s[j:k], s[k:]
-if v == "base":
+if v_apply == "base":
     pass
-elif v == "noexp":       # the transcendental replaced by a multiply
+elif v_apply == "noexp":       # the transcendental replaced by a multiply
     dq = rep(dq, "__builtin_amdgcn_exp2f(st[r] * c)", "(st[r] * c)"); dq = rep(dq, "__builtin_amdgcn_exp2f(st[r + 1] * c)", "(st[r + 1] * c)")
     dkv = rep(dkv, "__builtin_amdgcn_exp2f(st[r] * c)", "(st[r] * c)"); dkv = rep(dkv, "__builtin_amdgcn_exp2f(st[r + 1] * c)", "(st[r + 1] * c)")
-elif v == "novalu":      # no element work between the two MFMA groups: the accumulators are packed as they are
+elif v_apply == "novalu":      # no element work between the two MFMA groups: the accumulators are packed as they are
     dq = rep(dq, "                float d0, d1;\n                if (DROP) {", "                float d0, d1;\n                if (true) { d0 = st[r] + dp[r]; d1 = st[r + 1] + dp[r + 1]; } else if (DROP) {")
     dkv = rep(dkv, "                    if (DROP) {\n                        float m0, m1;", "                    if (true) { pp[r >> 1] = pack2_bf16(st[r], st[r + 1]); pd[r >> 1] = pack2_bf16(dp[r], dp[r + 1]); } else if (DROP) {\n                        float m0, m1;")
-elif v == "notr":        # the transposed fragments of the second MFMA group from registers instead of the LDS
+elif v_apply == "notr":        # the transposed fragments of the second MFMA group from registers instead of the LDS
     dq = rep(dq, "auto ldf = [&](int i) { fr[i] = tr_frag(Ks, kb * 32 + 16 * (i >> 1), i & 1, lane); };", "auto ldf = [&](int i) { fr[i] = __builtin_bit_cast(bf16x8, qf[i]); };")
     dkv = rep(dkv, "tr_frag(Os, qb * 32 + 16 * s, dt, lane)", "__builtin_bit_cast(bf16x8, vf[2 * s + dt])")
     dkv = rep(dkv, "tr_frag(Qs, qb * 32 + 16 * s, dt, lane)", "__builtin_bit_cast(bf16x8, kf[2 * s + dt])")
-elif v == "noqo":        # the A operands of the first MFMA group from registers instead of the LDS
+elif v_apply == "noqo":        # the A operands of the first MFMA group from registers instead of the LDS
     dq = rep(dq, "const f32x4 kf = *(const f32x4*)&Ks[tile_off(key, 2 * s + lh)];", "const f32x4 kf = qf[(s + 1) & 3];")
     dq = rep(dq, "const f32x4 vf = *(const f32x4*)&Vs[tile_off(key, 2 * s + lh)];", "const f32x4 vf = dof[(s + 1) & 3];")
     dkv = rep(dkv, "const f32x4 qa = *(const f32x4*)&Qs[tile_off(q, 2 * s + lh)];", "const f32x4 qa = kf[(s + 1) & 3];")
     dkv = rep(dkv, "const f32x4 oa = *(const f32x4*)&Os[tile_off(q, 2 * s + lh)];", "const f32x4 oa = vf[(s + 1) & 3];")
-elif v == "nomfma2":     # the second MFMA group (dQ; dV, dK) left out, its operands kept alive
+elif v_apply == "nomfma2":     # the second MFMA group (dQ; dV, dK) left out, its operands kept alive
     dq = rep(dq, "dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], dsf, dq[dt], 0, 0, 0);", 'asm volatile("" :: "v"(fr[i]), "v"(dsf));')
     dkv = rep(dkv, "dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Os, qb * 32 + 16 * s, dt, lane), pf, dv[dt],\n                                                                     0, 0, 0);", 'asm volatile("" :: "v"(tr_frag(Os, qb * 32 + 16 * s, dt, lane)), "v"(pf));')
     dkv = rep(dkv, "dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qs, qb * 32 + 16 * s, dt, lane), df, dk[dt],\n                                                                     0, 0, 0);", 'asm volatile("" :: "v"(tr_frag(Qs, qb * 32 + 16 * s, dt, lane)), "v"(df));')
-elif v == "nosync":      # no staging wait and no barrier at the end of a tile (the tiles race: timing only)
+elif v_apply == "nosync":      # no staging wait and no barrier at the end of a tile (the tiles race: timing only)
     dq = rep(dq, "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");   // this wave's pieces of tile kt + 1 have landed\n        __syncthreads();\n", "")
     dkv = rep(dkv, "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");   // this wave's pieces of tile qt + 1 have landed\n        __syncthreads();\n", "")
-elif v == "occ2":        # two waves per SIMD (256 registers each)
+elif v_apply == "occ2":        # two waves per SIMD (256 registers each)
     dq = rep(dq, "__launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel", "__launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel")
     dkv = rep(dkv, "__launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel", "__launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel")
 else:
