@@ -83,6 +83,31 @@ w("noepi_nobarrier_clock", clocked(nobar))
 # the cursors never move (every K step streams the same rows): the scalar work of advance() is gone
 noadv = rep(noepi, "        advance(cur0);                                                                               \\\n        advance(cur1);                                                                               \\\n", "")
 w("noepi_noadvance_clock", clocked(noadv))
+# what a 256 x 128 tile would cost per K step: the B1 half is neither streamed nor read nor multiplied (phases (a0, b1) and
+# (a1, b1) are gone, A0 / A1 / B0 still stream; the waits are approximate and the tiles race: timing only)
+halfn = noepi
+i0 = halfn.index("        /* phase 0: quadrant (a0, b0) */")
+i1 = halfn.index("    } while (0)\n\n    for (int G = 0; G < total_k; G += 2) {")
+halfn = halfn[:i0] + """        /* phase 0: (a0, b0) */                                                                      \\
+        read_a(4 * (s) + 0);                                                                         \\
+        issue_half(cur0, 3, 4 * ((s) ^ 1) + 3);                                                         \\
+        P8_VMCNT(6);                                                                                 \\
+        P8_BAR();                                                                                    \\
+        mfma_quad(0, 0, w0);                                                                         \\
+        P8_BAR();                                                                                    \\
+        /* phase 3: (a1, b0) */                                                                      \\
+        read_a(4 * (s) + 3);                                                                         \\
+        read_b(w1, 4 * ((s) ^ 1) + 1);                                                               \\
+        issue_half(cur1, 0, 4 * (s) + 0);                                                               \\
+        issue_half(cur1, 1, 4 * (s) + 1);                                                               \\
+        advance(cur0);                                                                               \\
+        advance(cur1);                                                                               \\
+        P8_VMCNT(6);                                                                                 \\
+        P8_BAR();                                                                                    \\
+        mfma_quad(1, 0, w0);                                                                         \\
+        P8_BAR();                                                                                    \\
+""" + halfn[i1:]
+w("noepi_halfn_clock", clocked(halfn))
 # wave priorities: (a) none at all, (b) the fragment reads + DMA issue of a phase above the other wave row's MFMAs
 noprio = rep(rep(s, "        __builtin_amdgcn_s_setprio(1);\n", ""), "        __builtin_amdgcn_s_setprio(0);\n", "")
 w("noprio_clock", clocked(noprio))
