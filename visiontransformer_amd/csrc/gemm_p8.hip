@@ -143,7 +143,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     struct Cursor {
         i32x4 a, w;       // raw buffer descriptors {base lo, base hi, num_records, flags}
-        unsigned soff;    // K byte offset inside the tile's rows
+        unsigned soff;    // NT: K byte offset inside the tile's rows (both operands); TT: byte offset of the step's token rows in A
+        unsigned soffw;   // TT: ... in W (the two row strides differ)
         int ts, kt;       // item sequence number of this block, K step inside the item
         int m0, n0, tok0; // TT: tile origin and first token row of the item
     };
@@ -157,30 +158,25 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
         r[3] = 0x00020000;
         return r;
     };
-    // TT: the descriptors follow the token rows of the K step.  Everything per step is 32-bit scalar arithmetic (a
-    // 64-bit product or division here costs more than the 256-cycle phase it sits in): base += 64 rows, and
-    // num_records = bytes from the base to the end of the matrix, saturated, 0 once the step lies beyond the last row.
+    // TT: the descriptors are rebased once per item (tile columns, first token row of the K slice) and cover everything from
+    // there to the end of the matrix; the K step's token rows are the SCALAR offset of the load.  The range check of a raw
+    // buffer load includes that offset (voffset + soffset + 16 > num_records reads as zeros, also with soffset beyond
+    // num_records; tools/probes/soffset_range.hip, both the VGPR and the LDS-DMA form), so token rows beyond K -- the tail of
+    // the last slice -- arrive as zeros and a K step costs one scalar add per operand.
     const unsigned stepA = 64u * (unsigned)p.lda * 2u, stepW = 64u * (unsigned)p.ldw * 2u;
     const int capA = (int)(0x7fffffffu / ((unsigned)p.lda * 2u)), capW = (int)(0x7fffffffu / ((unsigned)p.ldw * 2u));
     auto set_records_tt = [&](Cursor& c) {
-        const int left = c.ts < my_tiles ? p.K - (c.tok0 + c.kt * 64) : 0;     // token rows from this step to the end
+        const int left = c.ts < my_tiles ? p.K - c.tok0 : 0;     // token rows from the item's first one to the end
         c.a[2] = left <= 0 ? 0 : (left >= capA ? 0x7fffffff : left * p.lda * 2 - c.m0 * 2);
         c.w[2] = left <= 0 ? 0 : (left >= capW ? 0x7fffffff : left * p.ldw * 2 - c.n0 * 2);
-    };
-    auto add_base = [](i32x4& r, unsigned bytes) {
-        int lo = r[0], hi = r[1];      // (hipcc turns the C carry idiom into five scalar instructions; these are the two)
-        asm("s_add_u32 %0, %0, %2\n\ts_addc_u32 %1, %1, 0" : "+s"(lo), "+s"(hi) : "s"(bytes) : "scc");
-        r[0] = lo;
-        r[1] = hi;
     };
     auto set_tile = [&](Cursor& c) {
         if (c.ts < my_tiles) {
             const TileCoord tc = coord(c.ts);
             if (TT) {
                 c.m0 = tc.m0; c.n0 = tc.n0; c.tok0 = tc.split * KT * 64;
-                const long long tok = (long long)c.tok0 + (long long)c.kt * 64;
-                c.a = make_rsrc((const T*)p.A + tok * p.lda + c.m0, 0);
-                c.w = make_rsrc((const T*)p.W + tok * p.ldw + c.n0, 0);
+                c.a = make_rsrc((const T*)p.A + (long long)c.tok0 * p.lda + c.m0, 0);
+                c.w = make_rsrc((const T*)p.W + (long long)c.tok0 * p.ldw + c.n0, 0);
             } else {
                 c.a = make_rsrc((const T*)p.A + (size_t)tc.m0 * p.lda, (long long)(p.M - tc.m0) * p.lda * 2);
                 c.w = make_rsrc((const T*)p.W + (size_t)tc.n0 * p.ldw, (long long)PT * p.ldw * 2);
@@ -195,25 +191,19 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
     auto set_cursor = [&](Cursor& c, int gstep) {   // gstep: index of the K step in this block's stream
         c.ts = gstep / KT;
         c.kt = gstep - c.ts * KT;
-        c.soff = TT ? 0u : (unsigned)c.kt * 128u;
+        c.soff = TT ? (unsigned)c.kt * stepA : (unsigned)c.kt * 128u;
+        c.soffw = TT ? (unsigned)c.kt * stepW : c.soff;
         set_tile(c);
     };
     auto advance = [&](Cursor& c) {                 // next K step of the stream
         ++c.kt;
-        if (!TT) c.soff += 128u;
+        c.soff += TT ? stepA : 128u;
+        if (TT) c.soffw += stepW;
         if (c.kt == KT) {
             c.kt = 0;
-            c.soff = 0;
+            c.soff = c.soffw = 0;
             ++c.ts;
             set_tile(c);
-        } else if (TT) {
-            // next 64 token rows of the same item: the bases move on, the bytes left to the end of the matrix shrink by the
-            // same amount (never saturated: wgrad_p8_applies keeps K * ld * 2 below 2^31), 0 once the step lies beyond the
-            // last row -- 5 scalar instructions per operand instead of set_records_tt's multiplies and selects
-            add_base(c.a, stepA);
-            add_base(c.w, stepW);
-            c.a[2] = max(c.a[2] - (int)stepA, 0);
-            c.w[2] = max(c.w[2] - (int)stepW, 0);
         }
     };
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -225,7 +215,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs p) {
         for (int pc = 0; pc < 2; ++pc) {
             // M0 = LDS destination of the wave's 1 KiB piece (lane l lands at + 16 l); written in the same statement
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(dst + pc * 1024), "v"(isA ? voffA[h][pc] : voffW[h][pc]), "s"(isA ? c.a : c.w), "s"(c.soff)
+                         :: "s"(dst + pc * 1024), "v"(isA ? voffA[h][pc] : voffW[h][pc]), "s"(isA ? c.a : c.w),
+                            "s"(TT && !isA ? c.soffw : c.soff)
                          : "memory");
         }
     };
