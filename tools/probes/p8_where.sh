@@ -74,11 +74,16 @@ w("clock", clocked(s))
 w("noepi_clock", clocked(noepi))
 nobar = rep(noepi, "        __builtin_amdgcn_s_barrier();         \\\n", "        ;         \\\n")
 w("noepi_nobarrier", nobar)
-nodma = rep(noepi, '"s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds"', '""')
+def strip_dma(t):   # the DMA statement's instruction text (one or two string literals) becomes empty
+    import re
+    t2, n = re.subn(r'asm volatile\("s_mov_b32 m0, %0[^;]*?"\s*\n?\s*::', 'asm volatile("" ::', t, flags=re.S)
+    assert n == 1, n
+    return t2
+nodma = strip_dma(noepi)
 w("noepi_nodma", nodma)
 w("noepi_nodma_clock", clocked(nodma))
 w("noepi_noread_clock", clocked(noread))
-w("noepi_noread_nodma_clock", clocked(rep(noread, '"s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds"', '""')))
+w("noepi_noread_nodma_clock", clocked(strip_dma(noread)))
 w("noepi_nobarrier_clock", clocked(nobar))
 # the cursors never move (every K step streams the same rows): the scalar work of advance() is gone
 noadv = rep(noepi, "        advance(cur0);                                                                               \\\n        advance(cur1);                                                                               \\\n", "")
