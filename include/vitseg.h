@@ -190,6 +190,9 @@ int vitseg_op_wgrad_bf16(const void* dY, const void* X, float* dW, float* scratc
 /* lowres fp32 [B, C, g, g] -> logits fp32 [B, C, S, S] and/or mask uint8 [B, S, S] */
 int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask, int batch, int C, int g, int S,
                               void* stream);
+/* the adjoint (what autograd derives for F.interpolate(..., mode="bilinear", align_corners=False), classes.py:260):
+ * grad_logits fp32 [B, C, S, S] -> grad_lowres fp32 [B, C, g, g]; S a multiple of g; deterministic */
+int vitseg_op_upsample_bwd(const float* grad_logits, float* grad_lowres, int batch, int C, int g, int S, void* stream);
 
 /* ---- loss (replaces nn.CrossEntropyLoss()(logits, y), classes.py:268,280) ----
  * lowres: fp32 [B, C, g, g] low-resolution logits (VITSEG_BUF_LOWRES after vitseg_forward); target: class

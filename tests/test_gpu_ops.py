@@ -178,6 +178,26 @@ def test_upsample_sigmoid_argmax_bit_exact(B, C, g, S):
     assert torch.equal(mask, mask2)
 
 
+@pytest.mark.parametrize("B,C,g,S", [(2, 2, 32, 512), (1, 17, 14, 224), (1, 3, 16, 64), (2, 2, 64, 1024), (1, 1, 12, 96),
+                                     (1, 2, 9, 2304)])
+def test_upsample_backward_is_the_adjoint(B, C, g, S):
+    """grad of F.interpolate(z, (S, S), bilinear, align_corners=False) w.r.t. z (what autograd hands the reference's seg head,
+    model/CE/classes.py:260) in fp64 on the CPU against the HIP kernel: one block per row of cells up to S = 2048, the
+    one-wave-per-cell form beyond (last case); patch sizes 4 ... 256; twice the same bits (no atomics)."""
+    gl = _rand(B, C, S, S, seed=S + g + C)
+    z = torch.zeros(B, C, g, g, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.interpolate(z, size=(S, S), mode="bilinear", align_corners=False).backward(gl.double())
+    gd = gl.to(DEV)
+    out = torch.full((B, C, g, g), float("nan"), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_upsample_bwd(gd.data_ptr(), out.data_ptr(), B, C, g, S, _stream()))
+    out2 = torch.full((B, C, g, g), float("nan"), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_upsample_bwd(gd.data_ptr(), out2.data_ptr(), B, C, g, S, _stream()))
+    ref = z.grad
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-6 * max(1.0, ref.abs().max().item()) * (S // g), (err, ref.abs().max().item())   # fp32 sums of (S/g)^2 ... 4 (S/g)^2 terms
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("scale,delta,S,g", [(0.3, 1.0, 512, 32), (1.5, 1e-4, 512, 32), (6.0, 3e-3, 512, 32), (20.0, 1.0, 512, 32),
                                              (0.3, 0.0, 512, 32), (3.0, 1e-6, 1024, 64), (1.0, 0.5, 256, 16)])
 def test_upsample_mask_only_two_classes(scale, delta, S, g):

@@ -31,6 +31,11 @@ k = s.index("// ----------------------------------------------------------------
 head, dq, dkv, tail = s[:i], s[i:j], s[j:k], s[k:]
 if v_apply == "base":
     pass
+elif v_apply.startswith("stagger"):   # co-resident blocks of a CU start a third (two thirds) of a tile apart: N x 64 cycles per slot
+    n = int(v_apply[len("stagger"):])
+    delay = "    { const int slot = ((int)blockIdx.x >> 8) %% 3; for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(%d); }\n" % n
+    dq = rep(dq, "    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n", "    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n" + delay, 1)
+    dkv = rep(dkv, "    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n", "    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n" + delay, 1)
 elif v_apply == "noexp":       # the transcendental replaced by a multiply
     dq = rep(dq, "__builtin_amdgcn_exp2f(st[r] * c)", "(st[r] * c)"); dq = rep(dq, "__builtin_amdgcn_exp2f(st[r + 1] * c)", "(st[r + 1] * c)")
     dkv = rep(dkv, "__builtin_amdgcn_exp2f(st[r] * c)", "(st[r] * c)"); dkv = rep(dkv, "__builtin_amdgcn_exp2f(st[r + 1] * c)", "(st[r + 1] * c)")

@@ -24,7 +24,7 @@ BUF_TOKENS, BUF_LOWRES = 0, 1
 EXPORTS = [
     "vitseg_version", "vitseg_last_error", "vitseg_set_option", "vitseg_get_option", "vitseg_param_count", "vitseg_param_offset", "vitseg_cast_params_bf16",
     "vitseg_query_workspace", "vitseg_workspace_offset", "vitseg_forward", "vitseg_op_layernorm_f32",
-    "vitseg_op_linear_f32", "vitseg_op_attention_f32", "vitseg_op_upsample_argmax",
+    "vitseg_op_linear_f32", "vitseg_op_attention_f32", "vitseg_op_upsample_argmax", "vitseg_op_upsample_bwd",
     "vitseg_profile_enable", "vitseg_profile_collect", "vitseg_op_linear_bf16", "vitseg_op_attention_bf16",
     "vitseg_ce_scratch_bytes", "vitseg_ce_loss",
     "vitseg_train_workspace", "vitseg_forward_train", "vitseg_backward", "vitseg_adam_step",
@@ -95,6 +95,7 @@ def lib() -> C.CDLL:
         l.vitseg_op_attention_f16.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_attention_f32x3.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_upsample_argmax.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+        l.vitseg_op_upsample_bwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_ce_scratch_bytes.argtypes = [i32, i32]
         l.vitseg_ce_scratch_bytes.restype = sz
         l.vitseg_ce_loss.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]

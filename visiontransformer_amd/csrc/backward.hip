@@ -271,8 +271,9 @@ __device__ __forceinline__ void taps_bwd(int d, float scale, int n_in, int& i0, 
     w1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
     w0 = 1.f - w1;
 }
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ G, float* __restrict__ dZ, int B,
-                                                           int C, int g, int S) {
+// One wave per low-res cell (any S): each wave walks its cell's 3P x 3P window, 192-byte row pieces.
+__global__ __launch_bounds__(256) void upsample_bwd_cell_kernel(const float* __restrict__ G, float* __restrict__ dZ, int B,
+                                                                int C, int g, int S) {
     const int lane = threadIdx.x & 63;
     const size_t cell = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= (size_t)B * C * g * g) return;
@@ -300,6 +301,66 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     }
     acc = wave_sum(acc);
     if (lane == 0) dZ[cell] = acc;
+}
+// One block per ROW of cells (image-class plane bc, cell row y), S <= UPB_MAX_S (round 4; the cell form above read its
+// window in 192-byte pieces, 9x over, at 0.5 TB/s): the rows of G that carry weight for cell row y are read ONCE by the
+// block, whole and coalesced (thread t owns pixel columns t, t + 256, ...: col[X] = sum_Y wy(Y) G[Y][X], rows in
+// increasing Y), the column sums are parked in LDS and each cell adds its window of them in a fixed order (8 threads per
+// cell at g = 32, a fixed shuffle tree).  Deterministic; 403 MB instead of ~1.2 GB through the L2 at B = 64, C = 2.
+constexpr int UPB_MAX_S = 2048;
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ G, float* __restrict__ dZ, int B,
+                                                           int C, int g, int S) {
+    __shared__ float colsum[UPB_MAX_S];
+    const int tid = threadIdx.x;
+    const int y = (int)(blockIdx.x % g);
+    const size_t bc = blockIdx.x / g;
+    const int P = S / g;
+    const float scale = (float)g / (float)S;
+    const int Y0 = max(0, (y - 1) * P), Y1 = min(S, (y + 2) * P);
+    const float* Gp = G + bc * (size_t)S * S;
+    constexpr int NX = UPB_MAX_S / 256;
+    float acc[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) acc[i] = 0.f;
+    for (int Y = Y0; Y < Y1; ++Y) {
+        int i0, i1;
+        float w0, w1;
+        taps_bwd(Y, scale, g, i0, i1, w0, w1);
+        const float wy = (i0 == y ? w0 : 0.f) + (i1 == y ? w1 : 0.f);   // block-uniform
+        if (wy == 0.f) continue;
+        const float* row = Gp + (size_t)Y * S;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int X = tid + 256 * i;
+            if (X < S) acc[i] = fmaf(wy, row[X], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int X = tid + 256 * i;
+        if (X < S) colsum[X] = acc[i];
+    }
+    __syncthreads();
+    // tpc threads per cell (a power of two, <= 64 and <= 256 / min(g, 256)); cells in passes of 256 / tpc
+    int tpc = 1;
+    while (tpc < 64 && tpc * 2 * g <= 256) tpc *= 2;
+    const int sub = tid & (tpc - 1), cpp = 256 / tpc;
+    for (int x0 = 0; x0 < g; x0 += cpp) {
+        const int x = x0 + tid / tpc;
+        float a = 0.f;
+        if (x < g) {
+            const int X0 = max(0, (x - 1) * P), X1 = min(S, (x + 2) * P);
+            for (int X = X0 + sub; X < X1; X += tpc) {
+                int i0, i1;
+                float w0, w1;
+                taps_bwd(X, scale, g, i0, i1, w0, w1);
+                const float wx = (i0 == x ? w0 : 0.f) + (i1 == x ? w1 : 0.f);
+                a = fmaf(wx, colsum[X], a);
+            }
+        }
+        for (int o = tpc >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (x < g && sub == 0) dZ[(bc * g + y) * (size_t)g + x] = a;
+    }
 }
 
 // ---- seg_head.2 (1x1 conv) backward + ReLU backward --------------------------------------------
@@ -331,18 +392,26 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float* __restric
     for (int c = 0; c < C; ++c) partial[((size_t)blockIdx.x * C + c) * MID + j] = dw[c];
 }
 // db2[c] = sum over (b, t) of dZ[b,c,t]; one block per class
-__global__ __launch_bounds__(256) void head_bias_bwd_kernel(const float* __restrict__ dZ, float* __restrict__ db2, int B,
-                                                            int Np, int C) {
-    __shared__ float red[256];
-    const int c = blockIdx.x;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < B * Np; i += 256) {
-        const int b = i / Np, t = i - b * Np;
-        s += dZ[((size_t)b * C + c) * Np + t];
+__global__ __launch_bounds__(1024) void head_bias_bwd_kernel(const float* __restrict__ dZ, float* __restrict__ db2, int B,
+                                                             int Np, int C) {
+    // 1024 threads x 4 independent chains per class (256 threads x one chain was a 256-deep dependent load-add chain:
+    // 85 us for 0.5 MB); fixed order: chain j of thread t takes elements t + 1024 (4 k + j), then a fixed tree
+    __shared__ float red[1024];
+    const int c = blockIdx.x, n = B * Np;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4096) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + 1024 * j;
+            if (i < n) {
+                const int b = i / Np, t = i - b * Np;
+                s[j] += dZ[((size_t)b * C + c) * Np + t];
+            }
+        }
     }
-    red[threadIdx.x] = s;
+    red[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
@@ -587,7 +656,10 @@ int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is
 
 int launch_upsample_bwd(const float* G, float* dZ, int B, int C, int g, int S, hipStream_t s) {
     const size_t cells = (size_t)B * C * g * g;
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, G, dZ, B, C, g, S);
+    if (S <= UPB_MAX_S)
+        hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((size_t)B * C * g)), dim3(256), 0, s, G, dZ, B, C, g, S);
+    else
+        hipLaunchKernelGGL(upsample_bwd_cell_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, G, dZ, B, C, g, S);
     VITSEG_LAUNCH_CHECK("upsample_bwd");
     return VITSEG_OK;
 }
@@ -602,7 +674,7 @@ int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* 
     // scratch is [blocks][C*256]: column sums over the blocks
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C * MID + 63) / 64), dim3(1024), 0, s, scratch, dW2, blocks, C * MID);
     VITSEG_LAUNCH_CHECK("head1x1_bwd_finish");
-    hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(C), dim3(256), 0, s, dZ, db2, B, Np, C);
+    hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(C), dim3(1024), 0, s, dZ, db2, B, Np, C);
     VITSEG_LAUNCH_CHECK("head_bias_bwd");
     return VITSEG_OK;
 }

@@ -547,4 +547,10 @@ int vitseg_op_upsample_argmax(const float* lowres, float* logits, uint8_t* mask,
     return launch_upsample(lowres, logits, mask, batch, C, g, S, (hipStream_t)stream);
 }
 
+int vitseg_op_upsample_bwd(const float* grad_logits, float* grad_lowres, int batch, int C, int g, int S, void* stream) {
+    VITSEG_CHECK_ARG(grad_logits && grad_lowres && batch > 0 && C > 0 && g > 0 && S >= g && S % g == 0, VITSEG_EINVAL,
+                     "upsample_bwd: null pointer or bad geometry (S must be a multiple of g)");
+    return launch_upsample_bwd(grad_logits, grad_lowres, batch, C, g, S, (hipStream_t)stream);
+}
+
 }  // extern "C"
