@@ -198,6 +198,23 @@ def test_upsample_backward_is_the_adjoint(B, C, g, S):
     assert torch.equal(out, out2)
 
 
+def test_upsample_backward_adjoint_identity_full_size():
+    """BASELINE configs[2] size (B = 64, C = 2, 32 x 32 -> 512 x 512), where the fp64 autograd reference would take a while:
+    <upsample(z), G> = <z, upsample_bwd(G)> with the HIP forward kernel (itself bit-exact against ATen) on the left."""
+    B, C, g, S = 64, 2, 32, 512
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    z = torch.randn(B, C, g, g, generator=gen).to(DEV)
+    G = torch.randn(B, C, S, S, generator=gen).to(DEV)
+    up = torch.empty(B, C, S, S, device=DEV)
+    _lib.check(_lib.lib().vitseg_op_upsample_argmax(z.data_ptr(), up.data_ptr(), None, B, C, g, S, _stream()))
+    dz = torch.empty(B, C, g, g, device=DEV)
+    _lib.check(_lib.lib().vitseg_op_upsample_bwd(G.data_ptr(), dz.data_ptr(), B, C, g, S, _stream()))
+    lhs = (up.double() * G.double()).sum().item()
+    rhs = (z.double() * dz.double()).sum().item()
+    scale = (up.double() * G.double()).abs().sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * scale, (lhs, rhs, scale)   # fp32 rounding of 33 M products, not a structural difference
+
+
 @pytest.mark.parametrize("scale,delta,S,g", [(0.3, 1.0, 512, 32), (1.5, 1e-4, 512, 32), (6.0, 3e-3, 512, 32), (20.0, 1.0, 512, 32),
                                              (0.3, 0.0, 512, 32), (3.0, 1e-6, 1024, 64), (1.0, 0.5, 256, 16)])
 def test_upsample_mask_only_two_classes(scale, delta, S, g):
