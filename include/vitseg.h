@@ -308,12 +308,15 @@ int vitseg_op_attention_bwd_f32(const float* qkv, const float* dctx, float* ctx_
  * bits are generated once into this buffer and read by the three kernels -- the path vitseg_forward_train /
  * vitseg_backward take -- instead of being hashed per element in each of them; the masks are the same bits.
  * scratch: vitseg_attention_bwd_scratch_floats() floats (delta [B, A, Np + 1] + the per-block partial sums of the CLS
- * token's own gradients). */
+ * token's own gradients and of the column sums).
+ * dbias_qkv (optional, fp32 [3 D]): the column sums of dqkv over all rows = the gradient of the fused q|k|v bias
+ * (modeling_vit.py:207-222, qkv_bias=True), taken from the kernels' fp32 accumulators (patch rows) and the stored CLS rows. */
 size_t vitseg_attention_dropmask_bytes(int batch, int num_patches, int num_heads);
 size_t vitseg_attention_bwd_scratch_floats(int batch, int num_patches, int num_heads);
 int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_out, float* lse_out, float* scratch,
                                  void* dqkv, int batch, int num_patches, int num_heads, float dropout_p,
-                                 uint32_t dropout_seed, uint32_t dropout_stream, void* dropmask_words, void* stream);
+                                 uint32_t dropout_seed, uint32_t dropout_stream, void* dropmask_words, float* dbias_qkv,
+                                 void* stream);
 int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out,
                                 float* dw, float* db, float* scratch, int rows, int D, float eps, void* stream);
 

@@ -652,11 +652,24 @@ def test_attention_backward_bf16(B, Np, A, p):
     scr = torch.empty(_lib.lib().vitseg_attention_bwd_scratch_floats(B, Np, A), device=DEV)
     dqkv = torch.full((Mt, 3 * D), float("nan"), device=DEV, dtype=torch.bfloat16)
     mw = torch.empty(_lib.lib().vitseg_attention_dropmask_bytes(B, Np, A), dtype=torch.uint8, device=DEV) if words else None
+    dbias = torch.full((3 * D,), float("nan"), device=DEV)
     _lib.check(_lib.lib().vitseg_op_attention_bwd_bf16(qd.data_ptr(), dd.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
                                                        scr.data_ptr(), dqkv.data_ptr(), B, Np, A, p, seed, stream_id,
-                                                       mw.data_ptr() if words else None, _stream()))
+                                                       mw.data_ptr() if words else None, dbias.data_ptr(), _stream()))
     got, ref = dqkv.float().cpu().double(), x.grad
     assert torch.isfinite(got).all()
+    # the fused QKV bias gradient = the column sums of dqkv (the kernels sum their fp32 accumulators, the stored values are
+    # those rounded to bf16: the two differ by the rounding noise of Mt values per column), and the same bits without it
+    csum = got.sum(dim=0)
+    db = dbias.cpu().double()
+    assert torch.isfinite(db).all()
+    assert float((db - csum).norm() / got.abs().sum(dim=0).norm()) < 1e-3, float((db - csum).norm() / got.abs().sum(dim=0).norm())
+    assert float((db - ref.sum(dim=0)).norm() / ref.abs().sum(dim=0).norm()) < 5e-3
+    dqkv2 = torch.full((Mt, 3 * D), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().vitseg_op_attention_bwd_bf16(qd.data_ptr(), dd.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
+                                                       scr.data_ptr(), dqkv2.data_ptr(), B, Np, A, p, seed, stream_id,
+                                                       mw.data_ptr() if words else None, None, _stream()))
+    assert torch.equal(dqkv.view(torch.int16), dqkv2.view(torch.int16))
     assert (ctx.float().cpu().double() - ctx_ref).abs().max().item() < 4e-2
     # P, dS and the outputs are rounded to bf16 (2^-9): a few 1e-3 relative to the gradient scale, per slot
     for i, name in enumerate(("dq", "dk", "dv")):
@@ -697,7 +710,7 @@ def test_attention_backward_bf16_is_its_rounding_model(Np, A, spread, p):
     mw = torch.empty(_lib.lib().vitseg_attention_dropmask_bytes(B, Np, A), dtype=torch.uint8, device=DEV) if words else None
     _lib.check(_lib.lib().vitseg_op_attention_bwd_bf16(qd.data_ptr(), dd.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
                                                        scr.data_ptr(), dqkv.data_ptr(), B, Np, A, p, seed, stream_id,
-                                                       mw.data_ptr() if words else None, _stream()))
+                                                       mw.data_ptr() if words else None, None, _stream()))
     got = dqkv.float().cpu().double()
     assert torch.isfinite(got).all()
     # reference token order (CLS first) <- patches-first rows; [1, A, N, hd] views

@@ -45,7 +45,7 @@ if a.op == "attn_bwd":   # bf16 attention forward (with lse) + backward, optiona
     mw = torch.empty(L.vitseg_attention_dropmask_bytes(a.B, a.Np, a.A), dtype=torch.uint8, device=dev) if a.words else None
     run = lambda: _lib.check(L.vitseg_op_attention_bwd_bf16(qkv.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
                                                             scr.data_ptr(), dqkv.data_ptr(), a.B, a.Np, a.A, a.drop, 1234, 9,
-                                                            mw.data_ptr() if mw is not None else None, st))
+                                                            mw.data_ptr() if mw is not None else None, None, st))
     work = 14.0 * a.B * a.A * (a.Np + 1) ** 2 * 64   # 2 + 5 products of 2 N^2 hd
 elif a.op == "wgrad":   # dW[M,N] = dY^T X over K token rows, bf16 operands token-major
     dY = torch.randn(a.K, a.M, device=dev).to(torch.bfloat16)

@@ -123,7 +123,7 @@ def lib() -> C.CDLL:
         l.vitseg_op_attention_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
         l.vitseg_attention_bwd_scratch_floats.argtypes = [i32, i32, i32]
         l.vitseg_attention_bwd_scratch_floats.restype = sz
-        l.vitseg_op_attention_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
+        l.vitseg_op_attention_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
         l.vitseg_attention_dropmask_bytes.argtypes = [i32, i32, i32]
         l.vitseg_attention_dropmask_bytes.restype = C.c_size_t
         l.vitseg_op_layernorm_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]

@@ -103,6 +103,15 @@ __device__ __forceinline__ float dot_frag(const f32x4 (&a)[4], const f32x4 (&b)[
     return part + __shfl_xor(part, 32, 64);
 }
 
+// t summed over the 4 lanes of a quad, on every lane of it: two DPP quad permutes (lane ^ 1, lane ^ 2) folded into the adds
+// -- __shfl_xor compiles to ds_bpermute_b32 here, an LDS round trip per value and step (194 of them with 150 waits in each
+// kernel's tail before this)
+__device__ __forceinline__ float quad_sum(float t) {
+    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xb1, 0xf, 0xf, true));
+    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4e, 0xf, 0xf, true));
+    return t;
+}
+
 // Sum over the block's 128 tokens of per-token vectors.  Lane (li, lh) holds 32 channels {16 s + 8 lh + j} of ITS token's
 // vector as scale * (the bf16 fragment registers f).  Quad sums by DPP (2 steps), the 32 quad sums of the block (8 per
 // wave) as rows of `red` (32 x 64 floats per vector, in the tile buffers, which are free once the loop is over), 64
@@ -121,10 +130,7 @@ __device__ __forceinline__ void cls_stage(const f32x4 (&f)[4], float scale, floa
             t[2 * e + 1] = bf_hi(u) * scale;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            t[j] += __shfl_xor(t[j], 1, 64);
-            t[j] += __shfl_xor(t[j], 2, 64);
-        }
+        for (int j = 0; j < 8; ++j) t[j] = quad_sum(t[j]);
         if ((li & 3) == 0) {   // channels 16 s + 8 lh + 0..7: two 16-byte stores
             *(f32x4*)(row + 16 * s) = f32x4{t[0], t[1], t[2], t[3]};
             *(f32x4*)(row + 16 * s + 4) = f32x4{t[4], t[5], t[6], t[7]};
@@ -146,6 +152,26 @@ __device__ __forceinline__ void cls_finish(const float* red, float* out, int nv,
     }
 }
 
+// The same sum for per-token vectors that live in MFMA ACCUMULATORS (dQ^T, dK^T, dV^T: lane (li, lh) holds channels
+// 32 dt + 8 g4 + 4 lh + e of its token in register 4 g4 + e of acc[dt]): the block's share of a COLUMN SUM of dq | dk | dv,
+// i.e. of the QKV bias gradient -- formed here from the fp32 accumulators the kernels hold anyway instead of by a pass
+// over the 302 MB of dQKV they wrote (round 4).  Rows of `red` as in cls_stage; finish with cls_finish.
+__device__ __forceinline__ void col_stage(const f32x16 (&acc)[2], float scale, float* red, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    float* row = red + (wave * 8 + (li >> 2)) * 64 + 4 * lh;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                t[e] = quad_sum(acc[dt][4 * g4 + e] * scale);
+            }
+            if ((li & 3) == 0) *(f32x4*)(row + 32 * dt + 8 * g4) = f32x4{t[0], t[1], t[2], t[3]};
+        }
+}
+
 // ---------------------------------------------------------------------------------- dQ (patch queries)
 // MW (both MFMA kernels; with DROP, without RAGGED): keep bits from the precomputed words (common.hpp
 // attn_dropmask_words) instead of one hash per element.
@@ -155,6 +181,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
                                                                   const bf16_t* __restrict__ dctx,
                                                                   const float* __restrict__ lse,
                                                                   float* __restrict__ delta, float* __restrict__ clsp,
+                                                                  float* __restrict__ colp,
                                                                   bf16_t* __restrict__ dqkv, int B, int Np, int A,
                                                                   DropArgs dr, const unsigned* __restrict__ maskw) {
     static_assert(!MW || (DROP && !RAGGED), "mask words: dropout on, whole 128-token blocks");
@@ -344,6 +371,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
         cls_ds = ds;
         cls_pm = p * m;
     }
+    // the dQ third of the QKV bias gradient's partial record: from the accumulators while they are complete and still live
+    // (the tile buffers are free: every wave has passed the loop's last barrier and nothing below reads them as tiles)
+    if (colp) col_stage(dq, q_valid ? 0.125f : 0.f, (float*)&lds[0][0][0] + 4096, tid);   // block-uniform
     if (q_valid) {
         bf16_t* out = dqkv + q_row * ld + head * HD;
 #pragma unroll
@@ -367,6 +397,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const bf16_t* 
         cls_stage(dof, q_valid ? cls_pm : 0.f, red + 2048, tid);
         __syncthreads();
         cls_finish(red, rec + 64, 2, tid);
+        if (colp) cls_finish(red + 4096, colp + (rec - clsp), 1, tid);
     }
 }
 
@@ -376,7 +407,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
                                                                    const bf16_t* __restrict__ dctx,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ delta,
-                                                                   float* __restrict__ clsp,
+                                                                   float* __restrict__ clsp, float* __restrict__ colp,
                                                                    bf16_t* __restrict__ dqkv, int B, int Np, int A,
                                                                    DropArgs dr, const unsigned* __restrict__ maskw) {
     static_assert(!MW || (DROP && !RAGGED), "mask words: dropout on, whole 128-token blocks");
@@ -605,6 +636,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
             }
         cls_ds = ds;
     }
+    if (colp) {   // block-uniform: the dK and dV thirds of the bias gradient's partial record (see the dQ kernel)
+        col_stage(dk, k_valid ? 0.125f : 0.f, (float*)&lds[0][0][0] + 2048, tid);
+        col_stage(dv, k_valid ? 1.f : 0.f, (float*)&lds[0][0][0] + 4096, tid);
+    }
     if (k_valid) {
         bf16_t* outk = dqkv + k_row * ld + D + head * HD;
         bf16_t* outv = dqkv + k_row * ld + 2 * D + head * HD;
@@ -626,9 +661,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const bf16_t*
     {
         float* red = (float*)&lds[0][0][0];
         __syncthreads();   // every wave is done with the tiles
+        const size_t rec = (((size_t)b * A + head) * ((Np + TB - 1) / TB) + at.rt) * 192;
         cls_stage(kf, k_valid ? cls_ds : 0.f, red, tid);
         __syncthreads();
-        cls_finish(red, clsp + (((size_t)b * A + head) * ((Np + TB - 1) / TB) + at.rt) * 192, 1, tid);
+        cls_finish(red, clsp + rec, 1, tid);
+        if (colp) cls_finish(red + 2048, colp + rec + 64, 2, tid);
     }
 }
 
@@ -671,18 +708,43 @@ __global__ __launch_bounds__(64) void attn_bwd_cls_finish_kernel(const bf16_t* _
     dqkv[cls_row * ld + 2 * D + head * HD + d] = f32_to_bf16(av);
 }
 
+// d(qkv bias)[part D + 64 head + d] = the column sum of dq | dk | dv: the per-block partial records of the two MFMA kernels
+// (patch tokens, fp32) plus the B CLS rows as the finish kernel stored them, in a fixed order.  Block = (part, head), 256
+// threads = 4 groups x 64 channels.
+__global__ __launch_bounds__(256) void attn_bwd_bias_kernel(const float* __restrict__ colp, const bf16_t* __restrict__ dqkv,
+                                                            float* __restrict__ dbias, int B, int Np, int A) {
+    __shared__ float red[4][64];
+    const int d = threadIdx.x & 63, grp = threadIdx.x >> 6, head = blockIdx.x % A, part = blockIdx.x / A;
+    const int D = A * HD, ld = 3 * D, nrt = (Np + TB - 1) / TB;
+    float a0 = 0.f, a1 = 0.f;
+    for (int b = grp; b < B; b += 4) {
+        const float* rec = colp + ((size_t)b * A + head) * nrt * 192 + part * 64 + d;
+        int rt = 0;
+        for (; rt + 1 < nrt; rt += 2) {
+            a0 += rec[rt * 192];
+            a1 += rec[(rt + 1) * 192];
+        }
+        if (rt < nrt) a0 += rec[rt * 192];
+        a1 += bf16_to_f32(dqkv[((size_t)B * Np + b) * ld + part * D + head * HD + d]);   // the CLS row of image b
+    }
+    red[grp][d] = a0 + a1;
+    __syncthreads();
+    if (grp == 0) dbias[part * D + head * HD + d] = (red[0][d] + red[1][d]) + (red[2][d] + red[3][d]);
+}
+
 template <bool DROP>
 int launch_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* lse, float* dvec, bf16_t* dqkv, int B,
-               int Np, int A, DropArgs dr, hipStream_t s, const unsigned* maskw) {
+               int Np, int A, DropArgs dr, hipStream_t s, const unsigned* maskw, float* dbias) {
     const dim3 grid((unsigned)((Np + TB - 1) / TB) * A * B);  // 1-D: attn_tile() places the tiles
     float* clsp = dvec + (size_t)B * A * (Np + 1);            // per-block CLS partials behind the delta vector
+    float* colp = dbias ? clsp + (size_t)B * A * ((Np + TB - 1) / TB) * 192 : nullptr;   // ... column-sum partials behind them
 #define VITSEG_BWD(RG, MWORDS)                                                                                         \
     do {                                                                                                               \
         hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DROP, RG, MWORDS>), grid, dim3(256), 0, s, qkv, ctx, dctx, lse,    \
-                           dvec, clsp, dqkv, B, Np, A, dr, maskw);                                                     \
+                           dvec, clsp, colp, dqkv, B, Np, A, dr, maskw);                                               \
         VITSEG_LAUNCH_CHECK("attn_bwd_dq_bf16");                                                                       \
         hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DROP, RG, MWORDS>), grid, dim3(256), 0, s, qkv, dctx, lse, dvec,  \
-                           clsp, dqkv, B, Np, A, dr, maskw);                                                           \
+                           clsp, colp, dqkv, B, Np, A, dr, maskw);                                                     \
         VITSEG_LAUNCH_CHECK("attn_bwd_dkv_bf16");                                                                      \
     } while (0)
     if (Np % TB != 0) VITSEG_BWD(true, false);
@@ -692,22 +754,27 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const f
     hipLaunchKernelGGL(attn_bwd_cls_finish_kernel<DROP>, dim3(A, B), dim3(64), 0, s, qkv, dctx, lse, dvec, clsp, dqkv, B, Np,
                        A, dr);
     VITSEG_LAUNCH_CHECK("attn_bwd_cls_finish");
+    if (dbias) {
+        hipLaunchKernelGGL(attn_bwd_bias_kernel, dim3(3 * A), dim3(256), 0, s, colp, dqkv, dbias, B, Np, A);
+        VITSEG_LAUNCH_CHECK("attn_bwd_bias");
+    }
     return VITSEG_OK;
 }
 
 }  // namespace
 
-// floats of launch_attention_bwd_bf16's scratch: delta [B, A, Np + 1] + one [dq_cls | dk_cls | dv_cls][64] record per
-// 128-token block of every (image, head)
+// floats of launch_attention_bwd_bf16's scratch: delta [B, A, Np + 1] + one [dq_cls | dk_cls | dv_cls][64] record and one
+// [colsum dq | dk | dv][64] record (the QKV bias gradient's partials) per 128-token block of every (image, head)
 size_t attention_bwd_bf16_scratch_floats(int B, int Np, int A) {
-    return (size_t)B * A * ((size_t)(Np + 1) + (size_t)((Np + TB - 1) / TB) * 192);
+    return (size_t)B * A * ((size_t)(Np + 1) + (size_t)((Np + TB - 1) / TB) * 384);
 }
 
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dvec,
-                              void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s, const unsigned* maskw) {
+                              void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s, const unsigned* maskw,
+                              float* dbias) {
     VITSEG_CHECK_ARG(qkv && ctx && dctx && lse && dvec && dqkv, VITSEG_EINVAL, "attention_bwd_bf16: null pointer");
-    return dr.thresh ? launch_bwd<true>((const bf16_t*)qkv, (const bf16_t*)ctx, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s, maskw)
-                     : launch_bwd<false>((const bf16_t*)qkv, (const bf16_t*)ctx, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s, nullptr);
+    return dr.thresh ? launch_bwd<true>((const bf16_t*)qkv, (const bf16_t*)ctx, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s, maskw, dbias)
+                     : launch_bwd<false>((const bf16_t*)qkv, (const bf16_t*)ctx, (const bf16_t*)dctx, lse, dvec, (bf16_t*)dqkv, B, Np, A, dr, s, nullptr, dbias);
 }
 
 }  // namespace vitseg

@@ -111,11 +111,13 @@ int launch_attention_bwd_f32(const float* qkv, const float* ctx, const float* dc
 // attn_dropmask_words) -- used when dropout is on and Np % 128 == 0, otherwise the kernels hash per element
 int launch_attention_bf16(const void* qkv, void* ctx, float* lse, int B, int Np, int A, DropArgs dr, hipStream_t s,
                           bool f16 = false, const unsigned* maskw = nullptr);
-// dvec: scratch of attention_bwd_bf16_scratch_floats(B, Np, A) floats (delta + the per-block partials of the CLS token's gradients)
+// dvec: scratch of attention_bwd_bf16_scratch_floats(B, Np, A) floats (delta + the per-block partials of the CLS token's
+// gradients and of the column sums); dbias (optional): [3 D] fp32, the column sums of dqkv over all B (Np + 1) rows = the
+// gradient of the fused QKV bias, formed from the kernels' fp32 accumulators instead of by a pass over dqkv
 size_t attention_bwd_bf16_scratch_floats(int B, int Np, int A);
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dvec,
                               void* dqkv, int B, int Np, int A, DropArgs dr, hipStream_t s,
-                              const unsigned* maskw = nullptr);
+                              const unsigned* maskw = nullptr, float* dbias = nullptr);
 int launch_attn_dropmask(unsigned* W, int B, int Np, int A, DropArgs dr, hipStream_t s);
 
 // seg_head.2 (1x1 conv) on the ReLU'd mid features -> NCHW low-res logits (a11)

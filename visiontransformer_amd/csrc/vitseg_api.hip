@@ -495,7 +495,8 @@ size_t vitseg_attention_bwd_scratch_floats(int batch, int num_patches, int num_h
 
 int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_out, float* lse_out, float* scratch,
                                  void* dqkv, int batch, int num_patches, int num_heads, float dropout_p,
-                                 uint32_t dropout_seed, uint32_t dropout_stream, void* dropmask_words, void* stream) {
+                                 uint32_t dropout_seed, uint32_t dropout_stream, void* dropmask_words, float* dbias_qkv,
+                                 void* stream) {
     VITSEG_CHECK_ARG(qkv && dctx && ctx_out && lse_out && scratch && dqkv, VITSEG_EINVAL, "attention_bwd: null pointer");
     VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "attention_bwd: dropout_p %f", dropout_p);
     DropArgs d{};
@@ -517,7 +518,7 @@ int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_ou
     if (int rc = launch_attention_bf16(qkv, ctx_out, lse_out, batch, num_patches, num_heads, d, (hipStream_t)stream, false, mw))
         return rc;
     return launch_attention_bwd_bf16(qkv, ctx_out, dctx, lse_out, scratch, dqkv, batch, num_patches, num_heads, d,
-                                     (hipStream_t)stream, mw);
+                                     (hipStream_t)stream, mw, dbias_qkv);
 }
 
 int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out,
