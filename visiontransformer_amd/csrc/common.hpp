@@ -166,16 +166,41 @@ __device__ __forceinline__ float mask_select(unsigned long lanes, float v) {  //
 #endif
 }
 
+// Reductions over the 64 lanes of a wave, the result on every lane (wave-uniform).  Six DPP steps inside the vector ALU
+// -- lane ^ 1, lane ^ 2 (quad permutes), mirror within 8 and within 16 lanes (every lane then holds its row's value), the
+// row totals chained by row_bcast:15 / row_bcast:31 into lane 63 -- and one v_readlane.  (The __shfl_xor butterfly this
+// replaces in round 4 compiles to six DEPENDENT ds_bpermute_b32 per reduction, an LDS round trip each: LayerNorm forward
+// does two of them per row, its backward four.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VITSEG_DPP(x, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += VITSEG_DPP(v, 0xb1, 0xf);    // quad_perm [1, 0, 3, 2]
+    v += VITSEG_DPP(v, 0x4e, 0xf);    // quad_perm [2, 3, 0, 1]
+    v += VITSEG_DPP(v, 0x141, 0xf);   // row_half_mirror
+    v += VITSEG_DPP(v, 0x140, 0xf);   // row_mirror
+    v += VITSEG_DPP(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3 (the other rows add the 0 passed as `old`)
+    v += VITSEG_DPP(v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    // (a disabled row keeps its own value: max(v, v))
+#define VITSEG_DPP_KEEP(x, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (x)), __builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xf, false))
+    v = fmaxf(v, VITSEG_DPP_KEEP(v, 0xb1, 0xf));
+    v = fmaxf(v, VITSEG_DPP_KEEP(v, 0x4e, 0xf));
+    v = fmaxf(v, VITSEG_DPP_KEEP(v, 0x141, 0xf));
+    v = fmaxf(v, VITSEG_DPP_KEEP(v, 0x140, 0xf));
+    v = fmaxf(v, VITSEG_DPP_KEEP(v, 0x142, 0xa));
+    v = fmaxf(v, VITSEG_DPP_KEEP(v, 0x143, 0xc));
+#undef VITSEG_DPP_KEEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+#undef VITSEG_DPP
+#else
+__device__ __forceinline__ float wave_sum(float v) { return v; }
+__device__ __forceinline__ float wave_max(float v) { return v; }
+#endif
 
 // exact (erf) GELU, activations.py:78-83:  gelu(u) = u Phi(u),  Phi(u) = (1 + erf(u / sqrt 2)) / 2.
 // Evaluated through the COMPLEMENTARY error function of a = |u| / sqrt 2,  erfc(a) = 2^(-a Q(a)):
