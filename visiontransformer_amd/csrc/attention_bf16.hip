@@ -335,10 +335,7 @@ __global__ __launch_bounds__(1024) void attn_cls_bf16_kernel(const bf16_t* __res
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float pu = part[u];
-            pu += __shfl_xor(pu, 1, 64);
-            pu += __shfl_xor(pu, 2, 64);
-            pu += __shfl_xor(pu, 4, 64);
-            pu += __shfl_xor(pu, 8, 64);
+            pu = row16_sum(pu);   // (DPP: __shfl_xor compiles to ds_bpermute_b32)
             const int key = base + 64 * u + grp;
             if (sub == 0 && key < N) sc[key] = pu;
         }

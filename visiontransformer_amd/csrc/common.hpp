@@ -183,6 +183,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += VITSEG_DPP(v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), on every lane of the row: the first four steps of wave_sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += VITSEG_DPP(v, 0xb1, 0xf);
+    v += VITSEG_DPP(v, 0x4e, 0xf);
+    v += VITSEG_DPP(v, 0x141, 0xf);
+    v += VITSEG_DPP(v, 0x140, 0xf);
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
     // (a disabled row keeps its own value: max(v, v))
 #define VITSEG_DPP_KEEP(x, ctrl, rmask) \
@@ -199,6 +207,7 @@ __device__ __forceinline__ float wave_max(float v) {
 #undef VITSEG_DPP
 #else
 __device__ __forceinline__ float wave_sum(float v) { return v; }
+__device__ __forceinline__ float row16_sum(float v) { return v; }
 __device__ __forceinline__ float wave_max(float v) { return v; }
 #endif
 
