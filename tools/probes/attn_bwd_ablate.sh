@@ -43,6 +43,11 @@ elif v_apply == "notail":      # no CLS-token work at the end of a block (vector
     dkv = rep(dkv, "        cls_stage(kf, k_valid ? cls_ds : 0.f, red, tid);\n", "")
     dkv = rep(dkv, "        cls_finish(red, clsp + rec, 1, tid);\n", "")
     dkv = rep(dkv, "        const float pm = p * m, ds = p * fmaf(dpc, m, -delta[stat0 + Np]);\n#pragma unroll\n        for (int dt = 0; dt < 2; ++dt)", "        const float pm = p * m, ds = p * fmaf(dpc, m, -delta[stat0 + Np]);\n#pragma unroll\n        for (int dt = 0; dt < 0; ++dt)")
+elif v_apply == "nocls_stage":   # dQ kernel: no partial records of the CLS key's gradients (the vector update stays)
+    dq = rep(dq, "        cls_stage(qf, q_valid ? cls_ds : 0.f, red, tid);\n        cls_stage(dof, q_valid ? cls_pm : 0.f, red + 2048, tid);\n", "        if (cls_ds + cls_pm == 1.2345f) red[tid] = cls_ds;\n")
+    dq = rep(dq, "        cls_finish(red, rec + 64, 2, tid);\n", "")
+elif v_apply == "nocls_update":  # dQ kernel: no rank-1 update of dQ by the CLS key (the partial records stay)
+    dq = rep(dq, "        const float ds = p * fmaf(dpc, m, ndelta);\n#pragma unroll\n        for (int dt = 0; dt < 2; ++dt)\n#pragma unroll\n            for (int g4 = 0; g4 < 4; ++g4) {   // accumulator register", "        const float ds = p * fmaf(dpc, m, ndelta);\n#pragma unroll\n        for (int dt = 0; dt < 0; ++dt)\n#pragma unroll\n            for (int g4 = 0; g4 < 4; ++g4) {   // accumulator register")
 elif v_apply == "noexp":       # the transcendental replaced by a multiply
     dq = rep(dq, "__builtin_amdgcn_exp2f(st[r] * c)", "(st[r] * c)"); dq = rep(dq, "__builtin_amdgcn_exp2f(st[r + 1] * c)", "(st[r + 1] * c)")
     dkv = rep(dkv, "__builtin_amdgcn_exp2f(st[r] * c)", "(st[r] * c)"); dkv = rep(dkv, "__builtin_amdgcn_exp2f(st[r + 1] * c)", "(st[r + 1] * c)")
