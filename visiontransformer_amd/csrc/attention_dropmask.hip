@@ -21,12 +21,19 @@ __global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned* __restrict
     const unsigned myk = drop_key(dr.seed, dr.stream, (unsigned)(bh * (Np + 1) + qg * 32 + (lane & 31)));
     const unsigned thr_lo = dr.thresh, thr_hi = dr.thresh << 16;
     unsigned* out = W + ((size_t)(bh * nb + qg) * nb) * 32;
+    // the 32 row keys as scalars, once (inside the pair loop they cost a v_readlane and -- one scalar operand per VOP3 -- a
+    // v_mov per hash: the pair's 24-bit product is formed once and the key ADDED, the same bits as drop_pair_hash)
+    unsigned kj[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) kj[j] = __builtin_amdgcn_readlane(myk, j);
     for (int pi = threadIdx.x; pi < (Np >> 1); pi += 256) {
         unsigned w0 = 0, w1 = 0;
+        const unsigned prod = __umul24((unsigned)pi, 0x9E3779u);
 #pragma unroll
         for (int j = 31; j >= 0; --j) {
-            const unsigned kj = __builtin_amdgcn_readlane(myk, j);
-            const unsigned h = drop_pair_hash(kj, (unsigned)pi);
+            unsigned h = prod + kj[j];
+            h ^= h >> 15;
+            h *= 0x85EBCA6Bu;
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("v_cmp_ge_u16 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(w0) : "v"(h), "v"(thr_lo) : "vcc");
             asm volatile("v_cmp_ge_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(w1) : "v"(h), "v"(thr_hi) : "vcc");
