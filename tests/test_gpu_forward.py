@@ -340,6 +340,39 @@ def test_cls_split_k_path_parity_and_batch_invariance(precision):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_batch_invariance_at_the_headline_size(precision):
+    """BASELINE configs[1] geometry (ViT-B/16, 512 x 512, batch 32), where the oracle would take minutes: a size-independent
+    property instead -- the logits and the mask of an image do not depend on what else is in the batch.  Images 5 .. 8 of
+    a batch of 32 against the same four images as a batch of their own: bit for bit in fp32 (persistent GEMMs, attention and
+    the CLS side path all keep a row's summation order), to fp32-rounding level in bf16."""
+    cfg = ViTSegConfig(2, 16, 768, 12, 12, image_size=512)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=5).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 32, seed=9)).to(DEV)
+    m = ViTSegmentationModel(2, 16, 768, 12, 12, image_size=512, precision=precision, device=DEV).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        _, lg = m.predict_mask(x[:4].contiguous(), return_logits=True)
+        # random-init weights let one class win every pixel: shift class 1's bias by the median logit difference, so that the
+        # decision boundary runs through the images and the mask comparison is not one of constants
+        sd["seg_head.2.bias"] = sd["seg_head.2.bias"].clone()
+        sd["seg_head.2.bias"][1] += float((lg[:, 0] - lg[:, 1]).median())
+        m.load_state_dict(sd)
+        mask_all, logits_all = m.predict_mask(x, return_logits=True)
+        mask_4, logits_4 = m.predict_mask(x[5:9].contiguous(), return_logits=True)
+    assert torch.isfinite(logits_all).all()
+    assert 0.05 < float(mask_all.float().mean()) < 0.95
+    if precision == "fp32":   # the headline / parity path: one kernel family and one summation order per row at every batch size
+        assert torch.equal(logits_all[5:9], logits_4)
+        assert torch.equal(mask_all[5:9], mask_4)
+    else:
+        # 16-bit: the dispatcher picks tile shapes (and lets the CLS rows ride in the persistent kernel's last round or not)
+        # by the batch's row count, i.e. MFMA shapes with different internal summation trees: equal up to fp32 rounding of
+        # the accumulations, seen through the bf16 roundings behind them -- far inside the format's own error (3e-2)
+        assert (logits_all[5:9] - logits_4).abs().max().item() < 5e-3
+        assert float((mask_all[5:9] != mask_4).float().mean()) < 5e-3
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_graph_replay_equals_eager(precision):
     """predict_mask_graphed: the forward captured as a hipGraph gives the same bits as the eager launch sequence, for
     fresh inputs, interleaved batch sizes, and after a parameter update (re-capture)."""
