@@ -113,7 +113,7 @@ def traffic_profile(precision):
     return found[-1] if found else None
 
 
-def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.0):
+def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.0, n_images=2):
     """Times the oracle (CPU port of the reference model/CE path) on the first images of the batch
     and uses the same run as the live parity check of the GPU output."""
     from oracle import vitseg_oracle as O
@@ -121,7 +121,7 @@ def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VITSEG_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
-    n = min(2, images_np.shape[0])
+    n = min(n_images, images_np.shape[0])
     x = torch.from_numpy(images_np[:n])
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -141,15 +141,17 @@ def cpu_baseline(cfg, sd_np, images_np, gpu_logits, gpu_mask, seconds_budget=25.
 
 
 def parity_vs(gpu_logits, gpu_mask, logits, mask):
-    """GPU output of the first images against oracle logits / mask of the same images."""
+    """GPU output of the first images against oracle logits / mask of the same images.  `mask_mismatch_at_stable_pixels` must be
+    0: a stable pixel is one whose sigmoid -> first-max decision no logit move of 2 x the measured error can change
+    (oracle mask_stable, the criterion of tests/test_gpu_forward.py); `unstable_pixels` is the share that criterion exempts."""
+    from oracle import vitseg_oracle as O
     n = logits.shape[0]
     err = float((gpu_logits[:n].cpu() - logits).abs().max())
-    srt = logits.sort(dim=1, descending=True).values
-    solid = (srt[:, 0] - srt[:, 1]) > 1e-4
-    match_all = float((gpu_mask[:n].cpu().long() == mask).float().mean())
-    match_solid = float((gpu_mask[:n].cpu().long() == mask)[solid].float().mean())
-    return {"logits_max_abs_err": err, "mask_match": match_all, "mask_match_margin_gt_1e-4": match_solid,
-            "images_checked": n}
+    differ = gpu_mask[:n].cpu().long() != mask
+    stable = O.mask_stable(logits.float(), 2.0 * err + 1e-7)
+    return {"logits_max_abs_err": err, "mask_match": float((~differ).float().mean()),
+            "mask_mismatch_at_stable_pixels": int((differ & stable).sum()),
+            "unstable_pixels": float((~stable).float().mean()), "images_checked": n}
 
 
 def run_tiled(precision, native, B, rank, dev, steps, warmup, barrier, procedural_weights=True):
@@ -352,6 +354,97 @@ def bench_aux(args, rank, world, dev, barrier):
     barrier()
 
 
+# The reference's OWN published workload: nine (P, D, L, A) configurations, batch 4 x 224x224, 17 classes,
+# `Inference_Time` = seconds of model(batch) + .sigmoid() per image (model/CE/datasetTestViTmodel.py:97-109,174-186); hardware
+# unstated (CPU inferred).  Means of the nine committed model/CE/test/*/*_metrics.csv files.
+REF_PUBLISHED_S_PER_IMAGE = {0: 0.3494, 1: 0.1729, 2: 0.6114, 3: 0.4408, 4: 0.8934, 5: 1.4548, 6: 1.4813, 7: 3.1436, 8: 5.8727}
+
+
+def time_calls(fn, reps, rounds=5):
+    """median over `rounds` of the mean wall time of `reps` back-to-back calls (seconds per call)."""
+    out = []
+    for _ in range(rounds):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / reps)
+    return float(np.median(out))
+
+
+def bench_ref_grid(args, rank, world, dev, barrier):
+    """--workload ref_grid: the reference's published regime -- each configuration of predict.CONFIGURATIONS at batch 4 (what the
+    reference timed) and batch 1 (the worker's single-image call, testViTModel.py:92-126), 224x224, 17 classes: one step = one
+    forward of that batch -> fp32 logits + uint8 sigmoid/argmax mask, eager launch sequence and hipGraph replay; s/image beside
+    the published figure; FLOPs / time against the MFMA peak of the precision; kernel launches per forward (nodes of the graph);
+    the oracle (CPU port of the reference) on the same batch as parity check and CPU baseline."""
+    from visiontransformer_amd.config import ViTSegConfig
+    from visiontransformer_amd.predict import CONFIGURATIONS
+    prec = args.precision
+    peak = PEAK_TFLOPS[prec]
+    ids = sorted(CONFIGURATIONS) if args.grid_configs is None else [int(v) for v in args.grid_configs.split(",")]
+    batches = [4, 1] if args.batch is None else [args.batch]
+    grid, cpu_budget = [], 45.0
+    for cid in ids:
+        P, D, L, A = CONFIGURATIONS[cid]
+        cfg = ViTSegConfig(17, P, D, L, A, image_size=224)
+        model = ViTSegmentationModel(17, P, D, L, A, image_size=224, device=dev,
+                                     precision={"f32": "fp32", "bf16": "bf16", "f16": "fp16", "f32x3": "fp32x3"}[prec]).eval()
+        sd_np = synth.make_state_dict(cfg, seed=1)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        entry = {"id": cid, "config": f"P{P}H{D}A{A}", "layers": L, "tokens": cfg.seq_len,
+                 "published_s_per_image": REF_PUBLISHED_S_PER_IMAGE[cid], "gflops_per_image": round(cfg.forward_flops_per_image() / 1e9, 2)}
+        for B in batches:
+            images_np = synth.make_images(cfg, B, seed=0, first_image=rank * B)
+            x = torch.from_numpy(images_np).to(dev)
+            with torch.no_grad():
+                for _ in range(max(args.warmup, 2)):
+                    mask, logits = model.predict_mask(x, return_logits=True)
+                    model.predict_mask_graphed(x, return_logits=True)
+                reps = max(args.steps, 5)
+                t_eager = time_calls(lambda: model.predict_mask(x, return_logits=True), reps)
+                t_graph = time_calls(lambda: model.predict_mask_graphed(x, return_logits=True), reps)
+                gm, gl = model.predict_mask_graphed(x, return_logits=True)
+                same = bool(torch.equal(gm, mask) and torch.equal(gl, logits))
+            t = min(t_eager, t_graph)
+            e = {"ms_eager": round(t_eager * 1e3, 4), "ms_graph": round(t_graph * 1e3, 4), "s_per_image": t / B,
+                 "images_per_s": round(B / t, 1), "vs_published": round(REF_PUBLISHED_S_PER_IMAGE[cid] / (t / B), 1),
+                 "tflops": round(B * cfg.forward_flops_per_image() / t / 1e12, 2),
+                 "frac_of_peak": round(B * cfg.forward_flops_per_image() / t / 1e12 / peak, 4),
+                 "launches_per_forward": model.graph_nodes(B, True), "graph_bit_identical": same}
+            if rank == 0 and not args.no_cpu_baseline and B == batches[0] and cpu_budget > 0:
+                t0 = time.perf_counter()
+                base, parity, _ = cpu_baseline(cfg, sd_np, images_np, logits, mask, seconds_budget=min(cpu_budget, 12.0),
+                                               n_images=B)
+                cpu_budget -= time.perf_counter() - t0
+                e["cpu_baseline"], e["parity"] = base, parity
+            entry[f"batch{B}"] = e
+        grid.append(entry)
+        del model
+        torch.cuda.empty_cache()
+    barrier()
+    if rank == 0:
+        head = next((g for g in grid if g["id"] == 0), grid[0])
+        hb = head[f"batch{batches[0]}"]
+        out = {"metric": f"images/sec (224x224, batch {batches[0]}) ViT seg, the reference's nine published configurations",
+               "value": hb["images_per_s"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": min(hb["ms_eager"], hb["ms_graph"]), "higher_is_better": True, "scaling": "weak",
+               # BASELINE.md section 1 publishes s/image for exactly these configurations (hardware unstated, CPU inferred)
+               "vs_baseline": hb["vs_published"], "dtype": prec, "data": "synthetic",
+               "config": {"workload": f"{head['config']} (L{head['layers']}) seg inference, batch {batches[0]} x 224x224, 17 classes, {prec}: "
+                                      f"forward -> fp32 logits + uint8 mask (the reference's model/CE/test/*_metrics.csv regime); `grid` "
+                                      f"holds all configurations at batch {' and '.join(str(b) for b in batches)}",
+                          "batch_per_gpu": batches[0], "image_size": 224, "num_classes": 17},
+               "roofline": {"bound": "mfma", "achieved": hb["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": hb["frac_of_peak"],
+                            "traffic": None, "kernel": "whole forward (every launch of one step; per-kernel: profiles/r05_ref_grid_*)"},
+               "grid": grid}
+        if "cpu_baseline" in hb:
+            out["cpu_baseline"], out["parity"] = hb["cpu_baseline"], hb["parity"]
+        print(json.dumps(out), flush=True)
+    barrier()
+
+
 def run_train_steps(model, x, y, world, steps, warmup, prof_steps, barrier):
     """`warmup` untimed + `steps` timed training steps (LightningViTModel.training_step + backward + (N>1: RCCL all-reduce of
     the flat gradient arena) + Adam(lr=1e-5)), then `prof_steps` further steps with hipEvents on the launch stream around
@@ -521,7 +614,8 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f32", "bf16", "f16", "f32x3"])
     ap.add_argument("--classes", type=int, default=2, help="segmentation classes (BASELINE configs use 2; the reference's "
                                                            "dataset has 17: the decoder tail then writes 17.8 MB/image)")
-    ap.add_argument("--workload", default="b16_512", choices=["b16_512", "l16_1024_tiled", "l16_1024_native"],
+    ap.add_argument("--grid-configs", default=None, help="ref_grid: comma-separated ids of predict.CONFIGURATIONS (default: all nine)")
+    ap.add_argument("--workload", default="b16_512", choices=["b16_512", "l16_1024_tiled", "l16_1024_native", "ref_grid"],
                     help="b16_512 = BASELINE configs[1] (default, the headline metric); l16_1024_tiled = configs[4]; "
                          "l16_1024_native = the same images as one 4097-token sequence each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -535,7 +629,7 @@ def main():
     tiled = args.workload in ("l16_1024_tiled", "l16_1024_native")
     if args.precision is None:
         args.precision = "f16" if tiled else "f32"
-    if args.batch is None:
+    if args.batch is None and args.workload != "ref_grid":
         args.batch = 16 if tiled else 32
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -568,6 +662,8 @@ def main():
 
     if tiled:
         return bench_tiled(args, rank, world, dev, barrier)
+    if args.workload == "ref_grid":
+        return bench_ref_grid(args, rank, world, dev, barrier)
     if args.mode in ("prep", "eval"):
         return bench_aux(args, rank, world, dev, barrier)
 

@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define VITSEG_VERSION 100 /* 0.1.0 */
+#define VITSEG_VERSION 110 /* 0.1.1: vitseg_op_attention_bwd_bf16 gained dbias_qkv and a larger scratch (round 4); the
+                              small-batch ops (round 5).  Bindings should compare vitseg_version() with the header they were
+                              written against. */
 
 enum vitseg_status {
     VITSEG_OK = 0,
@@ -107,8 +109,10 @@ int vitseg_version(void);
 const char* vitseg_last_error(void);
 /* Dispatcher switches for A/B measurements and tests (which kernel family takes a GEMM, precomputed dropout words on or
  * off, ...): process-wide, read by the launch path with one atomic load.  Names (case-insensitive): no_f32p, no_p8,
- * no_h16p, no_ragged_p8, no_dropmask, dropw_limit_mb, upsample_global, bf16_tiles, f32p_noinl, gn, no_mask2.  Each starts from the
- * environment variable VITSEG_<NAME> as it was when the library was loaded (the launch path itself never calls getenv).
+ * no_h16p, no_ragged_p8, no_dropmask, dropw_limit_mb, upsample_global, bf16_tiles, f32p_noinl, gn, no_mask2, no_small,
+ * small_variant.  Each starts from the environment variable VITSEG_<NAME> as it was when the library was loaded (the launch
+ * path itself never calls getenv): a numeric value is taken as is (VITSEG_NO_P8=0 leaves the switch off), an empty or
+ * non-numeric value of an on/off switch means 1.
  * The reference has no counterpart: its dispatch is ATen's. */
 int vitseg_set_option(const char* name, long long value);
 int vitseg_get_option(const char* name, long long* value);
@@ -154,6 +158,22 @@ int vitseg_op_linear_f32_ex(const float* A, const float* W, const float* bias, c
                             uint32_t dropout_stream, void* stream);
 /* qkv: [B*Np + B, 3*A*64] rows as in the workspace; ctx: [B*Np + B, A*64] */
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream);
+/* ---- the small-batch fp32 route (fewer than 2048 token rows per forward; vitseg_forward takes it by itself) ----
+ * One linear layer as that route computes it.  The reduction is cut into vitseg_small_splits(N, K) chunks -- a function of
+ * the layer's shape only, so an output's bits do not depend on M -- each chunk one fp32 fmaf chain, the chunk sums added in
+ * chunk order, then the bias.
+ * epilogue 0 / 1 (bias / bias + exact GELU; needs vitseg_small_splits(N, K) == 1): C[M, N] written directly.
+ * vitseg_op_linear_resln_f32_small (the o_proj / fc2 step of a pre-LN block, modeling_vit.py:266-286): chunk slabs into
+ * `scratch` (>= vitseg_small_splits(N, K) * M * N floats), then ONE row kernel: X += chunk sums + bias (in place),
+ * H = LayerNorm(X; lnw, lnb, eps). */
+int vitseg_small_splits(int N, int K);
+int vitseg_op_linear_f32_small(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epilogue,
+                               void* stream);
+int vitseg_op_linear_resln_f32_small(const float* A, const float* W, const float* bias, float* X, const float* lnw,
+                                     const float* lnb, float* H, float* scratch, size_t scratch_floats, int M, int N, int K,
+                                     float eps, void* stream);
+/* attention core for short sequences (same arguments and layout as vitseg_op_attention_f32) */
+int vitseg_op_attention_f32_small(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream);
 /* bf16 operands (A, W as raw bf16 bits), fp32 accumulate; bias and R fp32.  C is bf16 for epilogues 0/1
  * (tensors that feed the next MFMA) and fp32 for epilogue 2 (the residual stream). */
 int vitseg_op_linear_bf16(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N,

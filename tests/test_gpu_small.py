@@ -1,0 +1,187 @@
+"""GPU (-m gpu): the small-batch fp32 route (csrc/small.hpp: fewer than 2048 token rows per forward -- the reference's own
+regime, batch 4 x 224x224 and the single-image worker call) -- each kernel through the C ABI against the oracle / fp64 on
+seeded inputs, every tile variant, and the property the route is built around: an output's bits do not depend on M."""
+import pytest
+import torch
+
+from oracle import vitseg_oracle as O
+from visiontransformer_amd import _lib, synth
+from visiontransformer_amd.config import ViTSegConfig
+from visiontransformer_amd.model import ViTSegmentationModel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NVARIANTS = 5
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def _linear_small(A, W, bias, epi):
+    M, K = A.shape
+    N = W.shape[0]
+    C = torch.full((M, N), float("nan"), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_linear_f32_small(A.data_ptr(), W.data_ptr(), bias.data_ptr(), C.data_ptr(), M, N, K, epi,
+                                                     _stream()))
+    return C
+
+
+# (M, N, K): the QKV / fc1 shapes of the reference's widths at 1, 4 and 8 images of 224x224 (197 tokens), a ragged N (the
+# Tiny/16 QKV: 576 = 4.5 x 128), one row, and a K of a single step
+@pytest.mark.parametrize("M,N,K", [(197, 2304, 768), (788, 3072, 768), (1576, 1536, 512), (788, 576, 192), (1, 3072, 1024),
+                                   (33, 100, 32), (785, 2304, 768)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_linear_small_direct_epilogues(M, N, K, epi):
+    """C = A W^T + bias (and exact GELU) against fp64, identical bits from every tile variant, and -- the k order being the
+    tile kernel's -- identical to the large-batch path's vitseg_op_linear_f32."""
+    A, W, bias = _rand(M, K, seed=M).to(DEV), _rand(N, K, seed=N + 1, scale=0.05).to(DEV), _rand(N, seed=7, scale=0.1).to(DEV)
+    ref = A.double() @ W.double().T + bias.double()
+    if epi == 1:
+        ref = O.gelu_erf(ref)
+    outs = []
+    for v in [0] + list(range(1, NVARIANTS + 1)):
+        with _lib.option("small_variant", v):
+            outs.append(_linear_small(A, W, bias, epi))
+    assert (outs[0].double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    big = torch.empty_like(outs[0])
+    with _lib.option("no_f32p", 1):
+        _lib.check(_lib.lib().vitseg_op_linear_f32(A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, big.data_ptr(), M, N, K,
+                                                   epi, _stream()))
+    if K < 512:   # (from K = 512 on the tile kernel cuts small shapes into K slices of its own: another order)
+        assert torch.equal(big, outs[0])
+
+
+def _resln(A, W, bias, X, lnw, lnb, eps=1e-12):
+    M, K = A.shape
+    N = W.shape[0]
+    S = _lib.lib().vitseg_small_splits(N, K)
+    scratch = torch.full((S * M * N,), float("nan"), device=DEV)
+    Xo, H = X.clone(), torch.full((M, N), float("nan"), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_linear_resln_f32_small(A.data_ptr(), W.data_ptr(), bias.data_ptr(), Xo.data_ptr(),
+                                                           lnw.data_ptr(), lnb.data_ptr(), H.data_ptr(), scratch.data_ptr(),
+                                                           scratch.numel(), M, N, K, eps, _stream()))
+    return Xo, H, S
+
+
+# o_proj / fc2 of the reference's three widths (chunked reductions: 3, 6, 2, 6, 4, 6 chunks) and the Tiny/16 o_proj (one)
+@pytest.mark.parametrize("M,N,K", [(197, 768, 768), (788, 768, 3072), (788, 512, 512), (197, 512, 3072), (394, 1024, 1024),
+                                   (788, 1024, 3072), (788, 192, 192)])
+def test_linear_resln_small(M, N, K):
+    """X += A W^T + bias; H = LayerNorm(X): fp64 reference, every tile variant identical, chunk count a function of (N, K)."""
+    A, W, bias = _rand(M, K, seed=M + 3).to(DEV), _rand(N, K, seed=N + 5, scale=0.05).to(DEV), _rand(N, seed=9, scale=0.1).to(DEV)
+    X, lnw, lnb = _rand(M, N, seed=13).to(DEV), (_rand(N, seed=15) * 0.1 + 1.0).to(DEV), _rand(N, seed=17, scale=0.1).to(DEV)
+    xr = X.double() + (A.double() @ W.double().T + bias.double())
+    hr = O.layer_norm(xr.cpu(), lnw.double().cpu(), lnb.double().cpu(), 1e-12)
+    Xo, H, S = _resln(A, W, bias, X, lnw, lnb)
+    assert S == {(768, 768): 3, (768, 3072): 6, (512, 512): 2, (512, 3072): 6, (1024, 1024): 4, (1024, 3072): 6, (192, 192): 1}[(N, K)]
+    assert (Xo.double() - xr).abs().max().item() < 3e-5 * max(1.0, xr.abs().max().item())
+    assert (H.double().cpu() - hr).abs().max().item() < 5e-5
+    for v in range(1, NVARIANTS + 1):
+        with _lib.option("small_variant", v):
+            Xv, Hv, _ = _resln(A, W, bias, X, lnw, lnb)
+        assert torch.equal(Xv, Xo) and torch.equal(Hv, H), v
+
+
+@pytest.mark.parametrize("N,K,epi", [(2304, 768, 0), (3072, 768, 1), (768, 3072, 2), (768, 768, 2)])
+def test_linear_small_rows_do_not_depend_on_the_batch(N, K, epi):
+    """Rows 0..196 of an 8-image batch (1576 rows) = the same rows run alone (197 rows) and inside 4 images (788 rows), bit
+    for bit -- tiles differ (small_plan picks per M), the summation order does not."""
+    W, bias = _rand(N, K, seed=N + 1, scale=0.05).to(DEV), _rand(N, seed=7, scale=0.1).to(DEV)
+    A = _rand(1576, K, seed=1).to(DEV)
+    lnw, lnb = (_rand(N, seed=15) * 0.1 + 1.0).to(DEV), _rand(N, seed=17, scale=0.1).to(DEV)
+    X = _rand(1576, N, seed=13).to(DEV)
+    outs = []
+    for M in (1576, 788, 197):
+        if epi == 2:
+            Xo, H, _ = _resln(A[:M].contiguous(), W, bias, X[:M].contiguous(), lnw, lnb)
+            outs.append(torch.cat([Xo[:197], H[:197]]))
+        else:
+            outs.append(_linear_small(A[:M].contiguous(), W, bias, epi)[:197])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def _attention_ref(qkv, B, Np, A):
+    """fp64 softmax(q k^T / 8) v on the patches-first row layout (patch token t of image b in row b Np + t, CLS in row B Np + b)."""
+    D = 64 * A
+    out = torch.zeros(qkv.shape[0], D, dtype=torch.float64)
+    q, k, v = qkv.double().split(D, dim=1)
+    for b in range(B):
+        rows = list(range(b * Np, (b + 1) * Np)) + [B * Np + b]
+        for h in range(A):
+            sl = slice(64 * h, 64 * h + 64)
+            p = torch.softmax(q[rows, sl] @ k[rows, sl].T * 0.125, dim=-1)
+            out[rows, sl] = p @ v[rows, sl]
+    return out
+
+
+@pytest.mark.parametrize("B,Np,A", [(1, 196, 12), (4, 196, 3), (2, 784, 2), (1, 1024, 2), (3, 16, 2), (1, 31, 1), (2, 127, 1)])
+def test_attention_small(B, Np, A):
+    rows, D = B * Np + B, 64 * A
+    qkv = _rand(rows, 3 * D, seed=B * 1000 + Np, scale=1.5).to(DEV)
+    ctx = torch.full((rows, D), float("nan"), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_attention_f32_small(qkv.data_ptr(), ctx.data_ptr(), B, Np, A, _stream()))
+    ref = _attention_ref(qkv.cpu(), B, Np, A)
+    assert (ctx.double().cpu() - ref).abs().max().item() < 2e-5
+    # the large-batch kernel on the same input: same function, different cut of the work
+    big = torch.empty_like(ctx)
+    _lib.check(_lib.lib().vitseg_op_attention_f32(qkv.data_ptr(), big.data_ptr(), B, Np, A, _stream()))
+    assert (ctx - big).abs().max().item() < 2e-5
+
+
+def test_attention_small_is_batch_invariant():
+    """Image 1 of a batch of 4 = that image alone (its rows re-packed into the patches-first layout of a batch of 1)."""
+    B, Np, A = 4, 196, 12
+    D = 64 * A
+    qkv = _rand(B * Np + B, 3 * D, seed=5, scale=1.5).to(DEV)
+    ctx = torch.empty((B * Np + B, D), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_attention_f32_small(qkv.data_ptr(), ctx.data_ptr(), B, Np, A, _stream()))
+    one = torch.cat([qkv[Np:2 * Np], qkv[B * Np + 1:B * Np + 2]]).contiguous()
+    c1 = torch.empty((Np + 1, D), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_attention_f32_small(one.data_ptr(), c1.data_ptr(), 1, Np, A, _stream()))
+    assert torch.equal(c1[:Np], ctx[Np:2 * Np]) and torch.equal(c1[Np], ctx[B * Np + 1])
+
+
+@pytest.mark.parametrize("P,D,L,A", [(16, 768, 2, 12), (16, 512, 2, 8), (8, 512, 1, 8), (16, 1024, 2, 16)])
+def test_small_route_equals_large_route_within_rounding_and_oracle(P, D, L, A):
+    """The whole forward at 2 x 224x224, 17 classes: small-batch route against the oracle (the fp32 gate: logits within 1e-3,
+    masks identical wherever the measured logit error cannot flip them) and against the large-batch kernels on the same
+    input (option no_small), which compute the same function with another summation order."""
+    cfg = ViTSegConfig(17, P, D, L, A, image_size=224)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=3).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 2, seed=1))
+    m = ViTSegmentationModel(17, P, D, L, A, image_size=224, device=DEV).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        mask, logits = m.predict_mask(x.to(DEV), return_logits=True)
+        with _lib.option("no_small", 1):
+            mask_l, logits_l = m.predict_mask(x.to(DEV), return_logits=True)
+        ref = O.forward(x, sd, cfg)
+    err = (logits.cpu() - ref).abs().max().item()
+    assert err < 1e-3 and (logits - logits_l).abs().max().item() < 1e-3, err
+    assert err < 2e-5, err   # measured: a few 1e-6
+    stable = O.mask_stable(ref, 2.0 * err + 1e-7)
+    assert int(((mask.cpu().long() != O.predict_mask(ref)) & stable).sum()) == 0 and float((~stable).float().mean()) < 2e-3
+
+
+def test_small_route_batch_invariance_vit_base():
+    """ViT-B/16 (2 layers) at 224x224: images 1..2 of a batch of 8 (1576 rows) = the same two images as a batch of 2, and image
+    0 = a batch of 1, bit for bit (logits and masks)."""
+    cfg = ViTSegConfig(17, 16, 768, 2, 12, image_size=224)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=3).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 8, seed=2)).to(DEV)
+    m = ViTSegmentationModel(17, 16, 768, 2, 12, image_size=224, device=DEV).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        m8, l8 = m.predict_mask(x, return_logits=True)
+        m2, l2 = m.predict_mask(x[1:3], return_logits=True)
+        m1, l1 = m.predict_mask(x[:1], return_logits=True)
+    assert torch.equal(l8[1:3], l2) and torch.equal(m8[1:3], m2)
+    assert torch.equal(l8[:1], l1) and torch.equal(m8[:1], m1)

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     l = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(l, name), name
-    assert _lib.lib().vitseg_version() == 100
+    assert _lib.lib().vitseg_version() == _lib.VERSION == 110
 
 
 def test_param_arena_layout_is_disjoint_and_complete():

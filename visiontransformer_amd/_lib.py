@@ -35,7 +35,9 @@ EXPORTS = [
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32", "vitseg_op_linear_h16_ex",
     "vitseg_op_wgrad_bf16", "vitseg_op_wgrad_bf16_scratch_floats", "vitseg_op_attention_bwd_bf16", "vitseg_attention_dropmask_bytes", "vitseg_attention_bwd_scratch_floats", "vitseg_op_colsum_scratch_floats",
     "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss", "vitseg_op_linear_f32_ex", "vitseg_resize_nearest_i64",
+    "vitseg_small_splits", "vitseg_op_linear_f32_small", "vitseg_op_linear_resln_f32_small", "vitseg_op_attention_f32_small",
 ]
+VERSION = 110   # include/vitseg.h VITSEG_VERSION this binding was written against
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
                 "head1x1", "upsample", "train_gemm_fwd", "train_dgrad", "train_wgrad", "train_attn_fwd", "train_attn_bwd"]
 
@@ -81,6 +83,10 @@ def lib() -> C.CDLL:
         l.vitseg_op_linear_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_op_linear_f32_ex.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, C.c_uint32, C.c_uint32, vp]
         l.vitseg_op_attention_f32.argtypes = [vp, vp, i32, i32, i32, vp]
+        l.vitseg_op_attention_f32_small.argtypes = [vp, vp, i32, i32, i32, vp]
+        l.vitseg_small_splits.argtypes = [i32, i32]
+        l.vitseg_op_linear_f32_small.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        l.vitseg_op_linear_resln_f32_small.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, C.c_float, vp]
         l.vitseg_op_linear_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
         l.vitseg_op_linear_f16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
@@ -131,6 +137,9 @@ def lib() -> C.CDLL:
         l.vitseg_profile_collect.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         for name in EXPORTS:
             getattr(l, name)  # raises AttributeError if the build is stale
+        if l.vitseg_version() != VERSION:   # argument lists changed between versions: a stale .so would misread them
+            raise RuntimeError(f"{LIB_PATH} is version {l.vitseg_version()}, this binding expects {VERSION}: rebuild it "
+                               "(python -m visiontransformer_amd.build)")
         _lib = l
     return _lib
 

@@ -33,6 +33,8 @@ enum Opt {
     OPT_F32P_NOINL,        // gemm_f32p: every epilogue at its tile's end
     OPT_GN,                // column-group width of the tile order (0: by shape)
     OPT_NO_MASK2,          // two-class mask-only upsample through the general kernel instead of upsample_mask2_kernel
+    OPT_NO_SMALL,          // fp32 forwards of fewer than 2048 token rows on the large-batch kernels instead of the small-batch route (small.hpp)
+    OPT_SMALL_VARIANT,     // gemm_f32s tile variant 1..5 for every launch (0: small_plan picks)
     OPT_COUNT
 };
 long opt(int id);

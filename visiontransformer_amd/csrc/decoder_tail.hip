@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     const float scale = (float)g / (float)S;
     int ymin = 0, nr = 0, Yf = 0, bimg = 0;
     if (STAGED) {
-        const int bpb = 256 / quads;                                   // bands per block (whole number, same image)
-        const size_t band0 = (size_t)blockIdx.x * bpb;
+        const int bpb = (int)blockDim.x / quads;                       // bands per block (whole number, same image; the block
+        const size_t band0 = (size_t)blockIdx.x * bpb;                 // has quads * bpb <= 256 threads, launch_upsample)
         Yf = (int)(band0 % bands) * UPR;
         bimg = (int)(band0 / bands);
         if (threadIdx.x == 0) amb_n = 0;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
         nr = yd - ya + 1;
         if (bimg < B) {
             const int per = nr * g;
-            for (int i = threadIdx.x; i < C * per; i += 256) {
+            for (int i = threadIdx.x; i < C * per; i += (int)blockDim.x) {
                 const int c = i / per, rem = i - c * per;
                 zs[i] = Z[((size_t)bimg * C + c) * g * g + (size_t)ymin * g + rem];
             }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     if (STAGED && mask) {
         __syncthreads();   // the queue is complete and this block's raw-argmax bytes are written
         const unsigned n_amb = amb_n;
-        for (unsigned i = threadIdx.x; i < n_amb; i += 256) {
+        for (unsigned i = threadIdx.x; i < n_amb; i += blockDim.x) {
             const int Y = Yf + (int)(amb_px[i] >> 12), X = (int)(amb_px[i] & 0xfffu);
             int ya, yb, xa, xb;
             float wya, wyb, wxa, wxb;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void upsample_mask2_kernel(const float* __rest
     __shared__ unsigned amb_px[256 * UPR * 4];
     const int quads = S >> 2, bands = S / UPR;
     const float scale = (float)g / (float)S;
-    const int bpb = 256 / quads;
+    const int bpb = (int)blockDim.x / quads;
     const size_t band0 = (size_t)blockIdx.x * bpb;
     const int Yf = (int)(band0 % bands) * UPR, bimg = (int)(band0 / bands);
     if (threadIdx.x == 0) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void upsample_mask2_kernel(const float* __rest
     __syncthreads();
     if (bimg < B) {
         unsigned mx = 0;
-        for (int i = threadIdx.x; i < per; i += 256) {
+        for (int i = threadIdx.x; i < per; i += (int)blockDim.x) {
             const float a = Z[((size_t)bimg * 2 + 0) * g * g + (size_t)ymin * g + i];
             const float b = Z[((size_t)bimg * 2 + 1) * g * g + (size_t)ymin * g + i];
             zs[i] = a;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void upsample_mask2_kernel(const float* __rest
     const float zmax = __uint_as_float(zmax_bits);
     // margin of upsample_kernel's rule + the rounding slack of D; no margin settles it once a logit may exceed 8
     const float thr = zmax <= 2.0f ? 1.1e-4f : (zmax <= 8.0f ? 4.01e-3f : INFINITY);
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int xq = (int)(idx % quads);
     const int Y0 = (int)((idx / quads) % bands) * UPR;
     if (bimg < B) {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void upsample_mask2_kernel(const float* __rest
     }
     __syncthreads();   // the queue is complete and this block's provisional bytes are written
     const unsigned n_amb = amb_n;
-    for (unsigned i = threadIdx.x; i < n_amb; i += 256) {
+    for (unsigned i = threadIdx.x; i < n_amb; i += blockDim.x) {
         const int Y = Yf + (int)(amb_px[i] >> 12), X = (int)(amb_px[i] & 0xfffu);
         int y0, y1, xa, xb;
         float wya, wyb, wxa, wxb;
@@ -451,21 +451,25 @@ int launch_upsample(const float* Z, float* logits, uint8_t* mask, int B, int C, 
     VITSEG_CHECK_ARG(S % 4 == 0 && C >= 1 && C <= 255, VITSEG_ESHAPE, "upsample: S %% 4 != 0 or C out of range");
     const size_t n = (size_t)B * (S / UPR) * (S / 4);
     const int quads = S / 4, bands = S / UPR;
-    // staged variant: a block must be whole bands of one image, and the source rows of its output rows must fit the LDS
-    const bool whole = quads <= 256 && 256 % quads == 0 && bands % (256 / quads) == 0;
-    const int rows_out = whole ? (256 / quads) * UPR : 0;
+    // staged variants: a block is a whole number of row bands of ONE image -- quads * bpb <= 256 threads, bpb | bands (S = 512:
+    // 2 bands = 256 threads; S = 224: 4 bands = 224 threads) -- and the source rows of its output rows must fit the LDS
+    int bpb = quads <= 256 ? 256 / quads : 0;
+    while (bpb > 1 && bands % bpb) --bpb;
+    const bool whole = bpb >= 1 && quads * bpb >= 128;
+    const int threads = whole ? quads * bpb : 256;
+    const int rows_out = whole ? bpb * UPR : 0;
     const size_t nr_max = (size_t)((double)rows_out * g / S) + 3;
     const size_t smem = (size_t)C * nr_max * g * sizeof(float);
+    const unsigned blocks_staged = whole ? (unsigned)((size_t)B * bands / bpb) : 0;
     if (whole && C == 2 && !logits && 3 * nr_max * g * sizeof(float) <= 32 * 1024 && !opt(OPT_UPSAMPLE_GLOBAL) &&
         !opt(OPT_NO_MASK2)) {   // mask-only, two classes: the class difference decides (upsample_mask2_kernel)
-        hipLaunchKernelGGL(upsample_mask2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 3 * nr_max * g * sizeof(float), s,
-                           Z, mask, B, g, S);
+        hipLaunchKernelGGL(upsample_mask2_kernel, dim3(blocks_staged), dim3(threads), 3 * nr_max * g * sizeof(float), s, Z, mask, B,
+                           g, S);
         VITSEG_LAUNCH_CHECK("upsample_mask2");
         return VITSEG_OK;
     }
     if (whole && smem <= 48 * 1024 && !opt(OPT_UPSAMPLE_GLOBAL))
-        hipLaunchKernelGGL(upsample_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), smem, s, Z, logits, mask, B,
-                           C, g, S);
+        hipLaunchKernelGGL(upsample_kernel<true>, dim3(blocks_staged), dim3(threads), smem, s, Z, logits, mask, B, C, g, S);
     else
         hipLaunchKernelGGL(upsample_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Z, logits, mask, B, C,
                            g, S);

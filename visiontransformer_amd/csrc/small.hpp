@@ -1,0 +1,79 @@
+// The SMALL-BATCH regime of the fp32 path: fewer than SMALL_MAX_ROWS token rows per forward -- the regime the reference
+// itself runs and publishes in (batch 4 x 224x224: 788 rows; model/CE/datasetTestViTmodel.py:97-109,174-186) and the
+// worker's single-image call (197 rows; model/CE/testViTModel.py:92-126).  At these sizes every GEMM of the large-batch
+// path is a fraction of one round of its 256x128 / 128x128 tiles; the kernels declared here cut the same arithmetic
+// differently (gemm_f32s.hip, rows_small.hip, attention_small.hip) and vitseg_small.hip strings them together.
+//
+// Summation order (what makes the results independent of the batch size inside the regime): a linear layer's reduction is
+// cut into small_splits(N, K) chunks -- a function of the layer's shape only, never of M -- each chunk is one fp32 fmaf
+// chain in the k order of gemm.hip's kernels (k = 32 kt + 8 j + 4 h + e), and the chunk sums are added in chunk order,
+// then the bias, then the residual.  Tile shapes are chosen per M (small_plan) and do not enter the order.
+#pragma once
+#include "kernels.hpp"
+
+namespace vitseg {
+
+constexpr int SMALL_MAX_ROWS = 2048;
+
+enum SmallEpi {
+    SE_PARTIAL = 0,   // C[s] = chunk sum s (no bias): consumed by resln_kernel / headfin_kernel
+    SE_BIAS = 1,      // C = acc + bias            (fused QKV projection; one chunk)
+    SE_GELU = 2       // C = gelu_erf(acc + bias)  (fc1; one chunk)
+};
+enum SmallAMode {
+    SA_PLAIN = 0,   // A[m * lda + k]
+    SA_CONV3 = 1,   // chunk s = tap (ky, kx) of the 3x3 head conv: rows of the token-major map shifted by the tap, zero outside
+    SA_PATCH = 2    // im2col of the NCHW image: row (b, gy, gx), k = (c, py, px)
+};
+
+struct SGemm {
+    const float* A;
+    const float* W;      // [N, ldw] row-major (nn.Linear layout); conv3: (out, ky, kx, in) = [256, 9 D]
+    const float* bias;   // [N] (SE_BIAS / SE_GELU)
+    float* C;            // [M, ldc], SE_PARTIAL: slab s at C + s * split_stride
+    int M, N, K;         // K: the whole reduction (conv3: per tap = D)
+    int lda, ldw, ldc;
+    int splits;          // chunks of K / splits values each (conv3: 9 taps)
+    size_t split_stride; // floats
+    int tiles_m, tiles_n, variant;   // filled by the launcher (small_plan)
+    int g, Np, S, P, Cin;            // geometry of SA_CONV3 / SA_PATCH
+};
+
+// chunks of a reduction of length K feeding N outputs per row (shape-only rule, see above)
+inline int small_splits(int N, int K) {
+    if (N > K) return 1;                       // wide outputs (QKV, fc1): enough tiles without a split, and fc1 needs GELU in the epilogue
+    const int chunk = K <= 1024 ? 256 : 512;   // o_proj (K = D): D / 256 chunks; fc2 (K = 3072): 6 chunks
+    return K % chunk == 0 && K > chunk ? K / chunk : 1;
+}
+int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s);
+
+// Rows kernel between the GEMMs: x = residual + (sum of the chunk slabs in order + bias), LayerNorm of the new row.
+//   embed != 0: the residual is the position embedding (rows < Mp: pos[1 + row % Np]); rows >= Mp are the CLS rows
+//   (cls + pos[0], no slabs).   ln_rows: rows [0, ln_rows) get their LayerNorm written to H (the final norm skips CLS).
+struct SRows {
+    float* X;                 // [rows, D] residual stream (read unless embed, written)
+    const float* partial;     // splits slabs of [rows, D]
+    size_t split_stride;
+    int splits;
+    const float* bias;        // [D]
+    const float* pos;         // embed: [Np + 1, D]
+    const float* cls;         // embed: [D]
+    const float* lnw;
+    const float* lnb;
+    float* H;                 // [rows, D]
+    int rows, Mp, Np, D, ln_rows, embed;
+    float eps;
+};
+int launch_resln(const SRows& a, hipStream_t s);
+
+// seg_head tail: F = relu(sum of the 9 tap slabs + b0) (256 mid channels), Z[b, c, y, x] = W2[c] . F + b2[c]
+int launch_headfin(const float* partial, size_t split_stride, const float* b0, const float* W2, const float* b2, float* Z,
+                   int B, int Np, int C, hipStream_t s);
+
+// softmax(q k^T / 8) v for short sequences: one block per 32 queries of one (image, head), the four waves split the keys
+int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s);
+
+// true when vitseg_forward takes the small-batch route
+bool small_applies(const vitseg_config* cfg, int batch, int precision);
+
+}  // namespace vitseg

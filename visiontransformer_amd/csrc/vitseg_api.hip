@@ -14,6 +14,7 @@
 #include "kernels.hpp"
 #include "profile.hpp"
 #include "plan.hpp"
+#include "small.hpp"
 
 namespace vitseg {
 
@@ -33,7 +34,8 @@ int hip_fail(hipError_t e, const char* what) {
 
 // ---- dispatcher switches (common.hpp Opt) ----
 static const char* const g_opt_names[OPT_COUNT] = {"no_f32p", "no_p8", "no_h16p", "no_ragged_p8", "no_dropmask",
-                                                   "dropw_limit_mb", "upsample_global", "bf16_tiles", "f32p_noinl", "gn", "no_mask2"};
+                                                   "dropw_limit_mb", "upsample_global", "bf16_tiles", "f32p_noinl", "gn", "no_mask2", "no_small",
+                                                   "small_variant"};
 static std::atomic<long> g_opts[OPT_COUNT];
 static int opt_index(const char* name) {
     if (!name) return -1;
@@ -41,10 +43,14 @@ static int opt_index(const char* name) {
         if (!strcasecmp(name, g_opt_names[i])) return i;
     return -1;
 }
-static long opt_parse(int id, const char* text) {   // environment form: presence = 1 for the switches
-    if (id == OPT_BF16_TILES) return text[0] == 's' ? 1 : text[0] == 'l' ? 2 : text[0] == 'x' ? 3 : atol(text);
-    if (id == OPT_DROPW_LIMIT_MB || id == OPT_GN) return atol(text);
-    return 1;
+// environment form: a number is taken as is (VITSEG_NO_P8=0 leaves the switch OFF, like vitseg_set_option("no_p8", 0));
+// an empty or non-numeric value of a boolean switch means 1 (VITSEG_NO_P8= , VITSEG_NO_P8=yes)
+static long opt_parse(int id, const char* text) {
+    if (id == OPT_BF16_TILES && (text[0] == 's' || text[0] == 'l' || text[0] == 'x')) return text[0] == 's' ? 1 : text[0] == 'l' ? 2 : 3;
+    char* end = nullptr;
+    const long v = strtol(text, &end, 10);
+    if (end != text) return v;
+    return (id == OPT_DROPW_LIMIT_MB || id == OPT_GN || id == OPT_SMALL_VARIANT || id == OPT_BF16_TILES) ? 0 : 1;
 }
 static const bool g_opts_loaded = [] {   // once, at library load
     for (int i = 0; i < OPT_COUNT; ++i) {
@@ -96,9 +102,96 @@ Plan make_plan(const Shape& s, int B, int precision) {
         const size_t need = (size_t)whole_split((int)p.Mt, nk[0], nk[1], 32) * p.Mt * nk[0];
         if (need > p.thin_floats) p.thin_floats = need;
     }
+    if (precision == VITSEG_F32 && p.Mt < (size_t)SMALL_MAX_ROWS) {   // K-chunk slabs of the small-batch route (small.hpp)
+        const size_t need[4] = {(size_t)small_splits(s.D, s.D) * p.Mt * s.D, (size_t)small_splits(s.D, s.I) * p.Mt * s.D,
+                                (size_t)small_splits(s.D, s.Kp) * p.Mt * s.D, (size_t)9 * p.Mp * MID};
+        for (size_t n : need)
+            if (n > p.thin_floats) p.thin_floats = n;
+    }
     p.thin = take(p.thin_floats * 4);
     p.total = off;
     return p;
+}
+
+// ---- the small-batch fp32 forward (small.hpp): fewer than SMALL_MAX_ROWS token rows ------------------------------
+// 7 launches per layer: QKV GEMM (+bias) | attention | o_proj chunks | chunk sum + bias + residual + LayerNorm |
+// fc1 GEMM (+bias, GELU) | fc2 chunks | chunk sum + bias + residual + the next LayerNorm.
+int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, const Plan& p, const float* params, const float* x,
+                  int batch, float* logits, uint8_t* mask, char* ws, hipStream_t st) {
+    auto W = [&](int t, int layer = 0) { return params + tensor_offset(lay, t, layer); };
+    float* X = (float*)(ws + p.x);
+    float* H = (float*)(ws + p.h);
+    float* QKV = (float*)(ws + p.qkv);
+    float* U = (float*)(ws + p.u);
+    float* Z = (float*)(ws + p.z);
+    float* part = (float*)(ws + p.thin);
+    const int Mt = (int)p.Mt, Mp = (int)p.Mp, D = s.D;
+    const size_t dstride = (size_t)Mt * D;   // slab stride of the D-wide chunk sums
+    int rc;
+    auto linear = [&](const float* A, int M, int K, int lda, int wt, int bt, int layer, float* C, int N, int epi, int kind) {
+        SGemm g{};
+        g.A = A; g.W = W(wt, layer); g.bias = W(bt, layer); g.C = C;
+        g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldc = N;
+        g.splits = epi == SE_PARTIAL ? small_splits(N, K) : 1;
+        g.split_stride = dstride;
+        ProfScope ps(kind, 2.0 * M * N * K, st);
+        return launch_gemm_f32s(g, epi, SA_PLAIN, st);
+    };
+    auto rows = [&](int splits, const float* bias, const float* lnw, const float* lnb, int ln_rows, bool embed) {
+        SRows r{};
+        r.X = X; r.partial = part; r.split_stride = dstride; r.splits = splits; r.bias = bias;
+        r.pos = W(VITSEG_T_POS); r.cls = W(VITSEG_T_CLS); r.lnw = lnw; r.lnb = lnb; r.H = H;
+        r.rows = Mt; r.Mp = Mp; r.Np = s.Np; r.D = D; r.ln_rows = ln_rows; r.embed = embed ? 1 : 0;
+        r.eps = cfg->layer_norm_eps;
+        ProfScope ps(VITSEG_K_LAYERNORM, (double)Mt * D * 4 * (2 + splits) + (double)ln_rows * D * 4, st);
+        return launch_resln(r, st);
+    };
+    // ---- embeddings (a2 + a3): patch projection chunks, then bias + position embedding + CLS rows + LayerNorm 1 of layer 0
+    {
+        SGemm g{};
+        g.A = x; g.W = W(VITSEG_T_PATCH_W); g.C = part;
+        g.M = Mp; g.N = D; g.K = s.Kp; g.lda = 0; g.ldw = s.Kp; g.ldc = D;
+        g.splits = small_splits(D, s.Kp); g.split_stride = dstride;
+        g.g = s.g; g.Np = s.Np; g.S = s.S; g.P = s.P; g.Cin = s.Cin;
+        {
+            ProfScope ps(VITSEG_K_GEMM_PATCH, 2.0 * g.M * g.N * g.K, st);
+            if ((rc = launch_gemm_f32s(g, SE_PARTIAL, SA_PATCH, st))) return rc;
+        }
+        if ((rc = rows(g.splits, W(VITSEG_T_PATCH_B), W(VITSEG_T_LN1_W, 0), W(VITSEG_T_LN1_B, 0), Mt, true))) return rc;
+    }
+    for (int l = 0; l < s.L; ++l) {
+        if ((rc = linear(H, Mt, D, D, VITSEG_T_WQKV, VITSEG_T_BQKV, l, QKV, 3 * D, SE_BIAS, VITSEG_K_GEMM_BIAS))) return rc;
+        {
+            ProfScope ps(VITSEG_K_ATTENTION, 4.0 * batch * s.A * (double)s.N * s.N * 64, st);
+            if ((rc = launch_attention_small(QKV, H, batch, s.Np, s.A, st))) return rc;
+        }
+        if ((rc = linear(H, Mt, D, D, VITSEG_T_WO, VITSEG_T_BO, l, part, D, SE_PARTIAL, VITSEG_K_GEMM_RESADD))) return rc;
+        if ((rc = rows(small_splits(D, D), W(VITSEG_T_BO, l), W(VITSEG_T_LN2_W, l), W(VITSEG_T_LN2_B, l), Mt, false))) return rc;
+        if ((rc = linear(H, Mt, D, D, VITSEG_T_W1, VITSEG_T_B1, l, U, s.I, SE_GELU, VITSEG_K_GEMM_GELU))) return rc;
+        if ((rc = linear(U, Mt, s.I, s.I, VITSEG_T_W2, VITSEG_T_B2, l, part, D, SE_PARTIAL, VITSEG_K_GEMM_RESADD))) return rc;
+        const bool last = l + 1 == s.L;   // the final LayerNorm covers the patch rows only (CLS is dropped, classes.py:250)
+        if ((rc = rows(small_splits(D, s.I), W(VITSEG_T_B2, l), last ? W(VITSEG_T_LNF_W) : W(VITSEG_T_LN1_W, l + 1),
+                       last ? W(VITSEG_T_LNF_B) : W(VITSEG_T_LN1_B, l + 1), last ? Mp : Mt, false)))
+            return rc;
+    }
+    // ---- seg_head (a10 + a11): the 3x3 conv as nine shifted GEMMs (one tap per chunk), then ReLU + the 1x1 conv
+    {
+        SGemm g{};
+        g.A = H; g.W = W(VITSEG_T_HEAD0_W); g.C = part;
+        g.M = Mp; g.N = MID; g.K = D; g.lda = D; g.ldw = 9 * D; g.ldc = MID;
+        g.splits = 9; g.split_stride = (size_t)Mp * MID;
+        g.g = s.g; g.Np = s.Np;
+        {
+            ProfScope ps(VITSEG_K_GEMM_CONV3, 2.0 * g.M * g.N * 9 * g.K, st);
+            if ((rc = launch_gemm_f32s(g, SE_PARTIAL, SA_CONV3, st))) return rc;
+        }
+        ProfScope ps(VITSEG_K_HEAD1X1, (double)Mp * MID * 4 * 9 + (double)batch * s.C * s.Np * 4, st);
+        if ((rc = launch_headfin(part, g.split_stride, W(VITSEG_T_HEAD0_B), W(VITSEG_T_HEAD2_W), W(VITSEG_T_HEAD2_B), Z, batch, s.Np, s.C, st)))
+            return rc;
+    }
+    const double px = (double)batch * s.S * s.S;
+    ProfScope ps(VITSEG_K_UPSAMPLE, (logits ? px * s.C * 4 : 0.0) + (mask ? px : 0.0) + (double)batch * s.C * s.Np * 4, st);
+    return launch_upsample(Z, logits, mask, batch, s.C, s.g, s.S, st);
 }
 
 }  // namespace
@@ -106,6 +199,14 @@ Plan make_plan(const Shape& s, int B, int precision) {
 Profiler& profiler() {
     static Profiler p;
     return p;
+}
+
+bool small_applies(const vitseg_config* cfg, int batch, int precision) {
+    Shape s;
+    if (precision != VITSEG_F32 || opt(OPT_NO_SMALL) || check_config(cfg, &s)) return false;
+    const long rows = (long)batch * s.N;
+    return rows < SMALL_MAX_ROWS && (s.P == 8 || s.P == 16 || s.P == 32) && s.D % 64 == 0 && s.I % 32 == 0 && s.I > s.D &&
+           s.Kp % 32 == 0 && s.S % 4 == 0;
 }
 }  // namespace vitseg
 
@@ -217,6 +318,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         return lp ? (const void*)((const unsigned short*)params_bf16 + off) : (const void*)(params + off);
     };
     char* ws = (char*)workspace;
+    if (small_applies(cfg, batch, precision)) return forward_small(cfg, s, lay, p, params, x, batch, logits, mask, ws, st);
     float* X = (float*)(ws + p.x);
     void* H = (void*)(ws + p.h);      // fp32 or bf16 by precision
     void* QKV = (void*)(ws + p.qkv);
@@ -537,6 +639,41 @@ int vitseg_op_attention_f16(const void* qkv, void* ctx, int batch, int num_patch
 
 int vitseg_op_attention_f32x3(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
     return launch_attention_f32(qkv, ctx, nullptr, batch, num_patches, num_heads, DropArgs{}, (hipStream_t)stream, true);
+}
+
+int vitseg_small_splits(int N, int K) { return small_splits(N, K); }
+
+int vitseg_op_linear_f32_small(const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K, int epilogue,
+                               void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && bias && C, VITSEG_EINVAL, "linear_f32_small: null pointer");
+    VITSEG_CHECK_ARG(epilogue == EPI_BIAS || epilogue == EPI_GELU, VITSEG_EINVAL, "linear_f32_small: epilogue %d", epilogue);
+    VITSEG_CHECK_ARG(small_splits(N, K) == 1, VITSEG_ESHAPE, "linear_f32_small: N=%d K=%d is a chunked shape (use linear_resln)", N, K);
+    SGemm g{};
+    g.A = A; g.W = Wt; g.bias = bias; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.splits = 1;
+    return launch_gemm_f32s(g, epilogue == EPI_GELU ? SE_GELU : SE_BIAS, SA_PLAIN, (hipStream_t)stream);
+}
+
+int vitseg_op_linear_resln_f32_small(const float* A, const float* Wt, const float* bias, float* X, const float* lnw,
+                                     const float* lnb, float* H, float* scratch, size_t scratch_floats, int M, int N, int K,
+                                     float eps, void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && bias && X && lnw && lnb && H && scratch, VITSEG_EINVAL, "linear_resln_f32_small: null pointer");
+    SGemm g{};
+    g.A = A; g.W = Wt; g.C = scratch;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
+    g.splits = small_splits(N, K);
+    g.split_stride = (size_t)M * N;
+    VITSEG_CHECK_ARG(scratch_floats >= g.splits * g.split_stride, VITSEG_EWORKSPACE, "linear_resln_f32_small: scratch %zu < %zu floats",
+                     scratch_floats, g.splits * g.split_stride);
+    if (int rc = launch_gemm_f32s(g, SE_PARTIAL, SA_PLAIN, (hipStream_t)stream)) return rc;
+    SRows r{};
+    r.X = X; r.partial = scratch; r.split_stride = g.split_stride; r.splits = g.splits; r.bias = bias;
+    r.lnw = lnw; r.lnb = lnb; r.H = H; r.rows = M; r.Mp = M; r.Np = M; r.D = N; r.ln_rows = M; r.embed = 0; r.eps = eps;
+    return launch_resln(r, (hipStream_t)stream);
+}
+
+int vitseg_op_attention_f32_small(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
+    return launch_attention_small(qkv, ctx, batch, num_patches, num_heads, (hipStream_t)stream);
 }
 
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {

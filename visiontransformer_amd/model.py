@@ -394,14 +394,29 @@ class ViTSegmentationModel(nn.Module):
                 for _ in range(2):
                     self._run(xs, return_logits, True, ws)
             torch.cuda.current_stream(xs.device).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
+            graph = torch.cuda.CUDAGraph(keep_graph=True)   # the hipGraph_t stays readable (graph_nodes)
             with torch.cuda.graph(graph):
                 logits, mask = self._run(xs, return_logits, True, ws)
+            graph.instantiate()
             g = dict(graph=graph, x=xs, ws=ws, logits=logits, mask=mask, ver=ver)
             self._graphs[key] = g
         g["x"].copy_(x, non_blocking=True)
         g["graph"].replay()
         return (g["mask"], g["logits"]) if return_logits else g["mask"]
+
+    def graph_nodes(self, batch: int, return_logits: bool = False) -> Optional[int]:
+        """Launches per forward = nodes of the hipGraph `predict_mask_graphed` captured for this batch size (None if it
+        has not been captured yet)."""
+        g = self._graphs.get((int(batch), bool(return_logits)))
+        if g is None:
+            return None
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipGraphGetNodes.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+        n = C.c_size_t()
+        rc = hip.hipGraphGetNodes(C.c_void_p(g["graph"].raw_cuda_graph()), None, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"hipGraphGetNodes failed with {rc}")
+        return int(n.value)
 
     @torch.no_grad()
     def predict_mask_tiled(self, x: torch.Tensor) -> torch.Tensor:
