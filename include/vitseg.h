@@ -172,6 +172,11 @@ int vitseg_op_linear_f32_small(const float* A, const float* W, const float* bias
 int vitseg_op_linear_resln_f32_small(const float* A, const float* W, const float* bias, float* X, const float* lnw,
                                      const float* lnb, float* H, float* scratch, size_t scratch_floats, int M, int N, int K,
                                      float eps, void* stream);
+/* diagnostics: vitseg_op_linear_f32_small with per-block time stamps written by the kernel (8 words per block: s_memrealtime
+ * at entry / exit, s_memtime at entry / after the prologue / after the K loop / at exit, HW_ID, XCC_ID; `stamps` must hold
+ * 8 words per launched block) and `lds_pad` extra bytes of LDS per block (limits the blocks per CU).  tools/small_stamps.py. */
+int vitseg_dbg_linear_f32_small(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epilogue,
+                                unsigned long long* stamps, int lds_pad, void* stream);
 /* attention core for short sequences (same arguments and layout as vitseg_op_attention_f32) */
 int vitseg_op_attention_f32_small(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream);
 /* bf16 operands (A, W as raw bf16 bits), fp32 accumulate; bias and R fp32.  C is bf16 for epilogues 0/1

@@ -69,7 +69,8 @@ def _asm(src, flags, tmp_path):
     return out.read_text()
 
 
-@pytest.mark.parametrize("src,flags", [("gemm_h16p.hip", []), ("gemm_f32p.hip", ["-fno-slp-vectorize"]), ("gemm_p8.hip", [])])
+@pytest.mark.parametrize("src,flags", [("gemm_h16p.hip", []), ("gemm_f32p.hip", ["-fno-slp-vectorize"]), ("gemm_p8.hip", []),
+                                       ("gemm_f32s.hip", [])])
 def test_persistent_gemms_do_not_spill(src, flags, tmp_path):
     """The persistent GEMMs order their LDS-DMA ring with hand-counted s_waitcnt vmcnt(N).  A register spill is a
     vector-memory instruction the counts do not know about, and hipcc's own wait for a reload ignores the DMA pieces in
@@ -96,6 +97,22 @@ def test_no_wide_buffer_store_with_scalar_offset(src, flags, tmp_path):
     bad = [l.strip() for l in _asm(src, flags, tmp_path).splitlines()
            if re.match(r"\s*buffer_store_dwordx[34]\b", l) and re.search(r",\s*s\d+\s+offen", l.split(";")[0])]
     assert not bad, bad[:4]
+
+
+def test_layernorm_backward_keeps_three_blocks_per_cu(tmp_path):
+    """backward.hip sizes the LayerNorm-backward grid as 3 resident 256-thread blocks per CU (launch_layernorm_bwd); that
+    holds while the <3, ...> instantiations stay within 168 registers (3 waves per SIMD) and use no scratch -- nothing at
+    run time would report a kernel that grew past it, it would only run a third of its blocks in a second round."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    text = _asm("backward.hip", [], tmp_path)
+    found = 0
+    for name, body in re.findall(r"\.amdhsa_kernel (\S*layernorm_bwd_kernelILi3\S*)(.*?)\.end_amdhsa_kernel", text, re.S):
+        nv = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        assert nv <= 168 and scratch == 0, (name, nv, scratch)
+        found += 1
+    assert found >= 1, "no layernorm_bwd_kernel<3, ...> instantiation found"
 
 
 def _vgprs(text):

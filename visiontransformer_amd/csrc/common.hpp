@@ -221,9 +221,11 @@ __device__ __forceinline__ float wave_max(float v) { return v; }
 // form is good to 6e-8 ABSOLUTE in Phi -- 8e-6 of the result at u = -3 -- and costs ~34 vector instructions (two
 // polynomials, an emulated expf, a select); erfc keeps the tail's RELATIVE precision and is one polynomial, one v_exp_f32
 // and a select: 18 instructions.  On the fp32 path every one of them is time added to the fp32 MFMAs.
-// Error against fp64 over ALL 2^32 inputs (tools/probes/gelu_check.hip): see DESIGN section 3; |error| <= 0.7e-6 of
-// max(|gelu|, 1e-2) -- the libm form: 8e-6.  gelu(+inf) = +inf, gelu(-huge) = -0, NaN stays NaN.
-__device__ __forceinline__ float gelu_erf(float u) {
+// Error against fp64 over ALL 2^32 inputs (tools/probes/gelu_check.hip, profiles/r04_gelu_check_all_2e32_inputs.txt):
+// max |error| / max(|gelu|, 1e-2) = 8.1e-7 (up to ~4400 ulps of the tiny results near u = -5, where the libm form is off by
+// 8e-6 of the same scale).  Once a q exceeds 126 (|u| > ~11.4, gelu < 1e-36) v_exp_f32 flushes the product to 0 instead of
+// returning a denormal: gelu is then exactly -0 or u.  gelu(+inf) = +inf, gelu(-huge) = -0, NaN stays NaN.
+__device__ __forceinline__ float gelu_phi(float u) {   // Phi(u) = (1 + erf(u / sqrt 2)) / 2
 #pragma clang fp contract(off)   // every fused multiply-add is spelled out: all kernels must agree bit for bit
     const float a = fabsf(u) * 0.70710678118654752440f;
     const float c = fminf(a, 5.0f);   // the fit's range; beyond it Q stays at Q(5) = 7.86 and erfc decays as 2^(-7.86 a)
@@ -237,14 +239,19 @@ __device__ __forceinline__ float gelu_erf(float u) {
     q = fmaf(c, q, __uint_as_float(0x3f6b1c07u));
     q = fmaf(c, q, __uint_as_float(0x3fd05f5fu));
     const float e = __builtin_amdgcn_exp2f(-(a * q));                  // erfc(a); 0 once a q > 149
-    const float w = u >= 0.f ? fmaf(e, -0.5f, 1.0f) : 0.5f * e;        // Phi(u); a NaN takes the second side and stays one
-    return u * w;
+    return u >= 0.f ? fmaf(e, -0.5f, 1.0f) : 0.5f * e;                 // a NaN takes the second side and stays one
+}
+__device__ __forceinline__ float gelu_erf(float u) {
+#pragma clang fp contract(off)
+    return u * gelu_phi(u);
 }
 
-// d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+// d/du [u * Phi(u)] = Phi(u) + u * phi(u), Phi from the SAME erfc evaluation as gelu_erf (the fp32 training path's forward
+// and its derivative are one function; the 1 + erff form this replaces cancels for u < 0: 8e-6 of the tail)
 __device__ __forceinline__ float gelu_erf_grad(float u) {
-    const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
-    return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+#pragma clang fp contract(off)
+    const float pdf = __builtin_amdgcn_exp2f((u * u) * -0.72134752044448170368f);   // exp(-u^2 / 2)
+    return fmaf(u * pdf, 0.39894228040143267794f, gelu_phi(u));
 }
 
 // GELU alone for tensors that are rounded to 16 bits right away (inference): erf by Abramowitz-Stegun 7.1.28,

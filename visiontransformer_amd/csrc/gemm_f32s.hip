@@ -38,18 +38,23 @@ constexpr Variant VARIANTS[] = {{1, 2, 2, 2, 3}, {1, 1, 1, 4, 4}, {1, 3, 2, 2, 3
 constexpr int NVARIANTS = sizeof(VARIANTS) / sizeof(VARIANTS[0]);
 
 template <int V, int EPI, int AMODE>
-__global__ __launch_bounds__(256) void gemm_f32s_kernel(const SGemm p) {
+__global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
     constexpr Variant CV = VARIANTS[V];
     constexpr int MT = CV.MT, NT = CV.NT, WGN = CV.WGN, NSTAGE = CV.NSTAGE;
     constexpr int BM = CV.bm(), BN = CV.bn();
     constexpr int STAGE = (BM + BN) * 128;
-    constexpr int PIECES = (BM + BN) / 8, PW = PIECES / 4;   // 1 KiB DMA pieces per stage / per wave
-    static_assert(PIECES % 4 == 0 && (NSTAGE - 2) * PW <= 63, "piece count");
+    constexpr int PIECES = (BM + BN) / 8;   // 1 KiB DMA pieces per K step
+    static_assert((NSTAGE - 2) * PIECES <= 63, "the loader's counted waits must fit the 6-bit vmcnt");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WGN, wc = wave % WGN;
-    const int li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3 compute, 4 = the loader
+    unsigned long long* stamp = p.stamps && tid == 0 ? p.stamps + (size_t)blockIdx.x * 8 : nullptr;   // diagnostics only
+    if (stamp) {
+        stamp[0] = __builtin_amdgcn_s_memrealtime();
+        stamp[2] = __builtin_amdgcn_s_memtime();
+        stamp[6] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+        stamp[7] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
+    }
 
     // block -> (row tile, column tile, chunk): row tiles fastest, so the blocks that share a W panel are neighbours in
     // the list and (xcd_remap) land on one XCD's L2; the whole A operand (< 8 MiB) lives in every L2 anyway
@@ -61,8 +66,6 @@ __global__ __launch_bounds__(256) void gemm_f32s_kernel(const SGemm p) {
     const int KT = kc / 32;
     const int k0w = sp * kc;                                    // first W column of this chunk
 
-    // ---- DMA side: piece q = rows [8 q, 8 q + 8) of the stage (A rows first), lane l -> row 8 q + (l >> 3), chunk position
-    // l & 7, which holds logical chunk (l & 7) ^ ((row >> 1) & 7) ----
     auto make_rsrc = [](const void* base, long long bytes) {
         const unsigned long long b = (unsigned long long)base;
         i32x4 r;
@@ -72,66 +75,95 @@ __global__ __launch_bounds__(256) void gemm_f32s_kernel(const SGemm p) {
         r[3] = 0x00020000;
         return r;
     };
-    constexpr unsigned OOB = 0x7ffffff0u;   // beyond every descriptor's range: reads as zeros
-    int dy = 0, dx = 0;
-    if (AMODE == SA_CONV3) {
-        dy = sp / 3 - 1;
-        dx = sp % 3 - 1;
-    }
-    unsigned voff[PW];
-    bool is_a[PW];
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        const int q = wave * PW + i;
-        const int row = 8 * q + (lane >> 3), pos = lane & 7;
-        is_a[i] = q < BM / 8;   // wave-uniform
-        if (is_a[i]) {
-            const int chunk = pos ^ ((row >> 1) & 7);
-            if (AMODE == SA_PLAIN) {
-                voff[i] = (unsigned)row * (unsigned)p.lda * 4u + (unsigned)(chunk * 16);
-            } else if (AMODE == SA_CONV3) {
-                const int r = m0 + row;
-                const int rem = r % p.Np, y = rem / p.g + dy, x = rem % p.g + dx;
-                const bool ok = r < p.M && y >= 0 && y < p.g && x >= 0 && x < p.g;
-                voff[i] = ok ? (unsigned)(r + dy * p.g + dx) * (unsigned)p.lda * 4u + (unsigned)(chunk * 16) : OOB;
-            } else {
-                const int r = m0 + row;
-                const int b = r / p.Np, rem = r % p.Np, gy = rem / p.g, gx = rem % p.g;
-                const int e4 = 4 * chunk;
-                voff[i] = r < p.M ? (unsigned)(((b * p.Cin) * p.S + gy * p.P + e4 / p.P) * p.S + gx * p.P + e4 % p.P) * 4u : OOB;
-            }
-        } else {
-            const int wrow = row - BM;
-            voff[i] = (unsigned)wrow * (unsigned)p.ldw * 4u + (unsigned)((pos ^ ((wrow >> 1) & 7)) * 16);
-        }
-    }
     const i32x4 ra = AMODE == SA_PLAIN ? make_rsrc(p.A + (size_t)m0 * p.lda, (long long)(p.M - m0) * p.lda * 4)
                      : AMODE == SA_CONV3 ? make_rsrc(p.A, (long long)p.M * p.lda * 4)
                                          : make_rsrc(p.A, (long long)(p.M / p.Np) * p.Cin * p.S * p.S * 4);
     const i32x4 rw = make_rsrc(p.W + (size_t)n0 * p.ldw, (long long)(p.N - n0) * p.ldw * 4);
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    // scalar byte offsets of K step kt: W columns k0w + 32 kt; A by mode
-    auto soff_a = [&](int kt) -> unsigned {
-        if (AMODE == SA_PLAIN) return (unsigned)(k0w + 32 * kt) * 4u;
-        if (AMODE == SA_CONV3) return (unsigned)(32 * kt) * 4u;
-        const int k = k0w + 32 * kt, pp = p.P * p.P;      // patch: k = (c, py, px); 32 | P^2 and P | 32 kt (P = 8, 16, 32)
-        return (unsigned)((k / pp) * p.S * p.S + ((k % pp) / p.P) * p.S) * 4u;
-    };
-#define F32S_DMA(dst, voff_, rsrc, soff)                                                               \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"            \
-                 :: "s"(dst), "v"(voff_), "s"(rsrc), "s"(soff) : "memory")
-    // piece i of this wave for K step kt into ring stage kt % NSTAGE
-    auto dma_piece = [&](int kt, int i) {
-        const unsigned sb = lds_base + (unsigned)((kt % NSTAGE) * STAGE) + (unsigned)((wave * PW + i) * 1024);
-        if (is_a[i]) F32S_DMA(sb, voff[i], ra, soff_a(kt));
-        else F32S_DMA(sb, voff[i], rw, (unsigned)(k0w + 32 * kt) * 4u);
-    };
-    auto dma_step = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) dma_piece(kt, i);
-    };
 
-    // ---- fragment side: lane (li, lh) reads 16-byte chunk (2 j + lh) ^ sw of row li of each 32-row MFMA tile ----
+    // Barrier protocol (all five waves): B0 = K step 0 has landed; B(kt + 1), kt = 0 .. KT - 2 = step kt + 1 has landed AND
+    // every compute wave holds its last fragments of step kt (its ring stage is free); one more after the loop (the ring is
+    // free for the epilogue's slabs).  The loader waits on its own vmcnt in front of each barrier; nobody else issues DMA.
+    if (wave == 4) {
+        // ---- the loader wave: the whole LDS-DMA stream of the block.  Issued from the compute waves (the first version of
+        // this kernel), a 1 KiB piece cost ~100 cycles of issue between two 64-cycle MFMAs and 5-8 pieces per step left the
+        // matrix pipe idle for 500-650 cycles of every K step (profiles/r05_small_stamps_1.txt); a wave that does nothing else
+        // issues a piece in ~25 ----
+        // piece q = rows [8 q, 8 q + 8) of the stage (A rows first); lane l -> row 8 q + (l >> 3), chunk position l & 7, which
+        // holds logical chunk (l & 7) ^ ((row >> 1) & 7)
+        constexpr unsigned OOB = 0x7ffffff0u;   // beyond every descriptor's range: reads as zeros
+        int dy = 0, dx = 0;
+        if (AMODE == SA_CONV3) {
+            dy = sp / 3 - 1;
+            dx = sp % 3 - 1;
+        }
+        unsigned voff[PIECES];
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            const int row = 8 * q + (lane >> 3), pos = lane & 7;
+            if (q < BM / 8) {
+                const int chunk = pos ^ ((row >> 1) & 7);
+                if (AMODE == SA_PLAIN) {
+                    voff[q] = (unsigned)row * (unsigned)p.lda * 4u + (unsigned)(chunk * 16);
+                } else if (AMODE == SA_CONV3) {
+                    const int r = m0 + row;
+                    const int rem = r % p.Np, y = rem / p.g + dy, x = rem % p.g + dx;
+                    const bool ok = r < p.M && y >= 0 && y < p.g && x >= 0 && x < p.g;
+                    voff[q] = ok ? (unsigned)(r + dy * p.g + dx) * (unsigned)p.lda * 4u + (unsigned)(chunk * 16) : OOB;
+                } else {
+                    const int r = m0 + row;
+                    const int b = r / p.Np, rem = r % p.Np, gy = rem / p.g, gx = rem % p.g;
+                    const int e4 = 4 * chunk;
+                    voff[q] = r < p.M ? (unsigned)(((b * p.Cin) * p.S + gy * p.P + e4 / p.P) * p.S + gx * p.P + e4 % p.P) * 4u : OOB;
+                }
+            } else {
+                const int wrow = row - BM;
+                voff[q] = (unsigned)wrow * (unsigned)p.ldw * 4u + (unsigned)((pos ^ ((wrow >> 1) & 7)) * 16);
+            }
+        }
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+        // scalar byte offsets of K step kt: W columns k0w + 32 kt; A by mode
+        auto soff_a = [&](int kt) -> unsigned {
+            if (AMODE == SA_PLAIN) return (unsigned)(k0w + 32 * kt) * 4u;
+            if (AMODE == SA_CONV3) return (unsigned)(32 * kt) * 4u;
+            const int k = k0w + 32 * kt, pp = p.P * p.P;      // patch: k = (c, py, px); 32 | P^2 and P | 32 kt (P = 8, 16, 32)
+            return (unsigned)((k / pp) * p.S * p.S + ((k % pp) / p.P) * p.S) * 4u;
+        };
+        auto dma_step = [&](int kt) {   // K step kt into ring stage kt % NSTAGE
+            const unsigned sb = lds_base + (unsigned)((kt % NSTAGE) * STAGE);
+            const unsigned sa = soff_a(kt), sw_ = (unsigned)(k0w + 32 * kt) * 4u;
+#pragma unroll
+            for (int q = 0; q < PIECES; ++q) {
+                if (q < BM / 8)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                                 :: "s"(sb + (unsigned)(q * 1024)), "v"(voff[q]), "s"(ra), "s"(sa) : "memory");
+                else
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                                 :: "s"(sb + (unsigned)(q * 1024)), "v"(voff[q]), "s"(rw), "s"(sw_) : "memory");
+            }
+        };
+        auto wait_landed = [&](int ahead) {   // all but the youngest `ahead` K steps have landed
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * PIECES >= 2 * PIECES ? 2 * PIECES : PIECES) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        int issued = 0;   // K steps issued so far
+        for (; issued < NSTAGE - 1 && issued < KT; ++issued) dma_step(issued);
+        wait_landed(issued - 1);
+        __builtin_amdgcn_s_barrier();   // B0
+        for (int kt = 0; kt + 1 < KT; ++kt) {
+            // behind B(kt) every compute wave has left stage (kt - 1) % NSTAGE: refill it, NSTAGE - 1 steps ahead
+            if (issued < KT) dma_step(issued++);
+            wait_landed(issued - 1 - (kt + 1));
+            __builtin_amdgcn_s_barrier();   // B(kt + 1)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // the ring is free
+        return;
+    }
+
+    // ---- compute waves: lane (li, lh) reads 16-byte chunk (2 j + lh) ^ sw of row li of each 32-row MFMA tile ----
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int li = lane & 31, lh = lane >> 5;
     const int sw = (li >> 1) & 7;
     int offj[4];
 #pragma unroll
@@ -152,68 +184,45 @@ __global__ __launch_bounds__(256) void gemm_f32s_kernel(const SGemm p) {
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    // chunk pair j (k = 8 j + 4 lh + e, e = 0..3) = four clusters of MT x NT MFMAs.  The DMA pieces of the step being
-    // prefetched go BETWEEN the clusters of groups 0..2, one at a time: issuing a piece takes about what one 64-cycle MFMA
-    // covers -- issued in a row at the top of the step (the first version of this loop) they left the matrix pipe idle for
-    // ~300 of a 1024-cycle step.  Piece i follows cluster (12 i) / PW of the step.
-    auto mfma_group = [&](int slot, int j, int kt_dma) {
+    auto mfma_group = [&](int slot) {   // chunk pair j: k = 8 j + 4 lh + e, e = 0..3
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][nt][e], fa[slot][mt][e], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < PW; ++i)
-                if ((12 * i) / PW == 4 * j + e && kt_dma >= 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    dma_piece(kt_dma, i);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-        }
-    };
-    auto wait_landed = [&](int ahead) {   // all but the youngest `ahead` K steps of this wave's DMA have landed
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * PW) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(PW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
 
-    // ---- prologue: steps 0 .. NSTAGE - 2 in flight, first fragments of step 0 ----
-#pragma unroll
-    for (int k = 0; k < NSTAGE - 1; ++k)
-        if (k < KT) dma_step(k);
-    wait_landed(min(NSTAGE - 2, KT - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();   // B0
     __builtin_amdgcn_sched_barrier(0);
     read_frags(0, 0, 0);
-
+    if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+    int st = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        const int st = kt % NSTAGE;
-        // every wave has passed the barrier of step kt - 1, i.e. finished reading stage (kt - 1) % NSTAGE: it is refilled
-        // with step kt + NSTAGE - 1 during groups 0..2
-        const int kd = kt + NSTAGE - 1 < KT ? kt + NSTAGE - 1 : -1;
+        const int nst = st + 1 == NSTAGE ? 0 : st + 1;
         read_frags(st, 1, 1);
-        mfma_group(0, 0, kd);
+        mfma_group(0);
         read_frags(st, 2, 0);
-        mfma_group(1, 1, kd);
+        mfma_group(1);
         read_frags(st, 3, 1);
-        mfma_group(0, 2, kd);
+        mfma_group(0);
         if (kt + 1 < KT) {
-            // step kt + 1 has landed for this wave and, behind the barrier, for every wave; all reads of stage st precede it
+            // the rotated barrier: all of this wave's reads of stage st are in registers, the next step's first fragments
+            // are read behind it under the last group's MFMAs
             __builtin_amdgcn_sched_barrier(0);
-            wait_landed(min(kt + NSTAGE - 1, KT - 1) - (kt + 1));
-            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // B(kt + 1)
             __builtin_amdgcn_sched_barrier(0);
-            read_frags((kt + 1) % NSTAGE, 0, 0);
+            read_frags(nst, 0, 0);
         }
-        mfma_group(1, 3, -1);
+        mfma_group(1);
+        st = nst;
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (stamp) stamp[4] = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();   // the ring is free: every wave parks its tiles in its own 4 KiB of it
-#undef F32S_DMA
 
     // ---- epilogue ----
     float* slab = (float*)(lds + wave * 4096);
@@ -247,6 +256,11 @@ __global__ __launch_bounds__(256) void gemm_f32s_kernel(const SGemm p) {
                 if (grow < p.M && gcol < p.N) *(f32x4*)(cbase + (size_t)grow * p.ldc + gcol) = v;
             }
         }
+    if (stamp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[5] = __builtin_amdgcn_s_memtime();
+        stamp[1] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // Least work on the busiest CU: a block's time is its MFMA stream (KT x MT x NT x 16 MFMAs of 64 cycles on each wave's
@@ -261,8 +275,10 @@ int small_plan(const SGemm& a, int kc, int amode) {
         const long blocks = (long)tm * tn * a.splits;
         const long per_cu = (blocks + ncu - 1) / ncu;
         const int occ = 163840 / V.lds() < 1 ? 1 : 163840 / V.lds();
-        const double stream = (double)(kc / 32) * V.MT * V.NT * 16 * 64;
-        const double fixed = 7000.0 + 1500.0 * V.MT * V.NT;   // cycles: launch ramp, first loads, parked epilogue
+        // measured with in-kernel stamps (tools/small_stamps.py, profiles/r05_small_stamps_*.txt): a K step costs its MFMAs
+        // (1024 cycles per tile) + ~200 for the barrier; prologue ~2700, epilogue ~1600 per tile, ~3000 of launch ramp
+        const double stream = (double)(kc / 32) * (V.MT * V.NT * 1024 + 200);
+        const double fixed = 5700.0 + 1600.0 * V.MT * V.NT;
         const double time = per_cu * stream + ((per_cu + occ - 1) / occ) * fixed;
         if (time < best) {
             best = time;
@@ -275,17 +291,18 @@ int small_plan(const SGemm& a, int kc, int amode) {
 
 template <int V, int EPI, int AMODE>
 int launch_one(const SGemm& a, hipStream_t s) {
-    constexpr int LDS = VARIANTS[V].lds();
+    constexpr int LDS0 = VARIANTS[V].lds();
+    const int LDS = LDS0 + (a.lds_pad > 0 && LDS0 + a.lds_pad <= 163840 ? a.lds_pad : 0);
     int dev = 0;
     static bool attr_set[64] = {};
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32s_kernel<V, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32s_kernel<V, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_f32s)");
         attr_set[dev] = true;
     }
     const int blocks = a.tiles_m * a.tiles_n * a.splits;
-    hipLaunchKernelGGL((gemm_f32s_kernel<V, EPI, AMODE>), dim3(blocks), dim3(256), LDS, s, a);
+    hipLaunchKernelGGL((gemm_f32s_kernel<V, EPI, AMODE>), dim3(blocks), dim3(320), LDS, s, a);
     VITSEG_LAUNCH_CHECK("gemm_f32s");
     return VITSEG_OK;
 }

@@ -37,6 +37,10 @@ struct SGemm {
     size_t split_stride; // floats
     int tiles_m, tiles_n, variant;   // filled by the launcher (small_plan)
     int g, Np, S, P, Cin;            // geometry of SA_CONV3 / SA_PATCH
+    // diagnostics (tools/small_stamps.py; null in the product path): 8 words per block -- s_memrealtime at entry and exit,
+    // s_memtime at entry / after the prologue / after the K loop / at exit, HW_ID, XCC_ID
+    unsigned long long* stamps;
+    int lds_pad;                     // extra dynamic LDS bytes per block (experiments: forces fewer blocks per CU)
 };
 
 // chunks of a reduction of length K feeding N outputs per row (shape-only rule, see above)

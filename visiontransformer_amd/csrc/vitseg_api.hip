@@ -643,6 +643,18 @@ int vitseg_op_attention_f32x3(const float* qkv, float* ctx, int batch, int num_p
 
 int vitseg_small_splits(int N, int K) { return small_splits(N, K); }
 
+// diagnostics (tools/small_stamps.py): the direct-epilogue small GEMM with per-block time stamps (8 words per block,
+// small.hpp SGemm::stamps; `stamps` holds >= 8 * blocks words, blocks <= M / 32 * N / 64 + ...: the caller sizes generously)
+int vitseg_dbg_linear_f32_small(const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K, int epilogue,
+                                unsigned long long* stamps, int lds_pad, void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && bias && C && stamps, VITSEG_EINVAL, "dbg_linear_f32_small: null pointer");
+    SGemm g{};
+    g.A = A; g.W = Wt; g.bias = bias; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.splits = 1;
+    g.stamps = stamps; g.lds_pad = lds_pad;
+    return launch_gemm_f32s(g, epilogue == EPI_GELU ? SE_GELU : SE_BIAS, SA_PLAIN, (hipStream_t)stream);
+}
+
 int vitseg_op_linear_f32_small(const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K, int epilogue,
                                void* stream) {
     VITSEG_CHECK_ARG(A && Wt && bias && C, VITSEG_EINVAL, "linear_f32_small: null pointer");
