@@ -445,7 +445,7 @@ def bench_ref_grid(args, rank, world, dev, barrier):
     barrier()
 
 
-def run_train_steps(model, x, y, world, steps, warmup, prof_steps, barrier):
+def run_train_steps(model, x, y, world, steps, warmup, prof_steps, barrier, sync=True):
     """`warmup` untimed + `steps` timed training steps (LightningViTModel.training_step + backward + (N>1: RCCL all-reduce of
     the flat gradient arena) + Adam(lr=1e-5)), then `prof_steps` further steps with hipEvents on the launch stream around
     the GEMM / attention launches (outside the timed region, so the event records do not perturb the timing).
@@ -457,10 +457,16 @@ def run_train_steps(model, x, y, world, steps, warmup, prof_steps, barrier):
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = model.ce_loss(x, y, grad_scale=1.0)   # the factor is folded into the CE gradient: no arena-sized multiply
-        loss.backward()
-        sync_grads(model)
-        opt.step(grad_scale=1.0 / world)
+        if sync:
+            loss = model.ce_loss(x, y, grad_scale=1.0)   # the factor is folded into the CE gradient: no arena-sized multiply
+            loss.backward()
+            sync_grads(model)
+            opt.step(grad_scale=1.0 / world)
+        else:   # the same step with the gradient exchange switched off (model.no_sync(): local gradients only) -- what the
+            with model.no_sync():   # all-reduce costs on top of the compute is the difference to the synchronised step
+                loss = model.ce_loss(x, y, grad_scale=1.0)
+                loss.backward()
+            opt.step(grad_scale=1.0)
         return loss
 
     for _ in range(warmup):
@@ -559,6 +565,117 @@ def side_train_bf16(cfg, sd_np, x32, dev, steps=5):
     return out
 
 
+def side_train_dist(cfg, sd_np, rank, world, dev, barrier, batch=64, steps=4):
+    """N > 1 (every rank, after the timed inference region): what BASELINE configs[3] shards -- the ViT-B/16 training step, batch
+    `batch` per rank x 512x512, bf16 operands / fp32 master + Adam, dropout 0.1, data-parallel with the bucketed gradient
+    all-reduce (RCCL over xGMI under the driver's launch) overlapped with the backward -- timed with the exchange and, the same
+    step, under model.no_sync(); the difference is the communication the overlap does not hide.  Replaces the single-device
+    loop of /root/reference/model/CE/createViTmodel.py:68-75."""
+    import torch.distributed as dist
+    model = ViTSegmentationModel(cfg.num_classes, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+                                 cfg.num_attention_heads, image_size=cfg.image_size, precision="bf16", dropout=0.1, device=dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    x = torch.from_numpy(synth.make_images(cfg, batch, seed=0, first_image=rank * batch)).to(dev)
+    y = torch.from_numpy(synth.make_targets(cfg, batch, seed=0, first_image=rank * batch, size=cfg.image_size)).to(dev)
+    res = {}
+    for key, sync in (("ms_per_step", True), ("ms_per_step_no_sync", False)):
+        elapsed, _, loss = run_train_steps(model, x, y, world, steps, 2, 0, barrier, sync=sync)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res[key] = float(t.item()) / steps * 1e3
+    reducer = model._bucket_state()[0] if model._buckets is not None else None
+    out = {"workload": f"ViT-B/16 seg TRAINING step (forward + CE + backward + gradient all-reduce + Adam), batch {batch}/GPU x 512x512, "
+                       f"bf16 operands / fp32 master + Adam, dropout 0.1 (BASELINE.json configs[3] at {world} ranks)",
+           "batch_per_gpu": batch, "global_batch": batch * world, "ranks_seen": dist.get_world_size(),
+           "collective": collective_name(world), "backend": str(dist.get_backend()),
+           "ms_per_step": round(res["ms_per_step"], 3), "ms_per_step_no_sync": round(res["ms_per_step_no_sync"], 3),
+           "exposed_communication_ms": round(res["ms_per_step"] - res["ms_per_step_no_sync"], 3),
+           "images_per_s": round(world * batch / (res["ms_per_step"] * 1e-3), 1),
+           "gradient_bytes_per_step": int(model.arena.numel()) * 4,
+           "all_reduce_messages_per_step": len(reducer.groups) if reducer is not None else 1,
+           "grad_sync": model.grad_sync, "final_loss": float(loss.detach())}
+    del model, x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def side_serve(dev, seconds=6.0):
+    """The worker's request path end to end on the device (rows f3 + path + f4 of SURVEY.md section 8 chained; contract:
+    /root/reference/backend/core/views.py:97-149, body modelled on model/CE/testViTModel.py:92-126): decoded uint8 photos
+    (3024 x 4032 RGB, resident in HBM) -> Preprocessor.images (Pillow-exact Resize((224, 224)) + ToTensor) -> ViT-B/16,
+    17 classes, fp32 predict_mask -> Evaluator.counts against a 256 x 256 label map.  Throughput at batch 8, latency per
+    single-image request (synchronised after each), and the mask of one request against the oracle run on the same photo
+    (Pillow on the host -> oracle forward -> sigmoid / first-max argmax)."""
+    from oracle import vitseg_oracle as O
+    from visiontransformer_amd.config import ViTSegConfig
+    from visiontransformer_amd.metrics import Evaluator
+    from visiontransformer_amd.preprocess import Preprocessor
+    H, W, S, C, NB = 3024, 4032, 224, 17, 8
+    cfg = ViTSegConfig(C, 16, 768, 12, 12, image_size=S)
+    sd_np = synth.make_state_dict(cfg, seed=1)
+    model = ViTSegmentationModel(C, 16, 768, 12, 12, image_size=S, device=dev).eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    rs = np.random.RandomState(11)
+    # smooth synthetic "photos" (low-frequency colour fields + noise), so the resize has something to average
+    base = rs.randint(0, 256, size=(NB, H // 48, W // 48, 3)).astype(np.uint8)
+    host = np.repeat(np.repeat(base, 48, axis=1), 48, axis=2)
+    host = np.clip(host.astype(np.int16) + rs.randint(-12, 13, size=host.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+    photos = torch.from_numpy(host).to(dev)
+    gt = torch.from_numpy(rs.randint(0, C, size=(NB, 256, 256), dtype=np.uint8)).to(dev)
+    pre, ev = Preprocessor(S, dev), Evaluator(C, dev)
+
+    def request(lo, hi):
+        x = pre.images(photos[lo:hi])
+        mask = model.predict_mask(x)
+        return mask, ev.counts(mask, gt[lo:hi])
+
+    with torch.no_grad():
+        for _ in range(3):
+            request(0, NB)
+            request(0, 1)
+        torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds / 2:
+            for _ in range(10):
+                request(0, NB)
+            torch.cuda.synchronize()
+            n += 10 * NB
+        thr = n / (time.perf_counter() - t0)
+        lat = []
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < seconds / 2 or len(lat) < 50:
+            i = len(lat) % NB
+            ta = time.perf_counter()
+            mask1, _ = request(i, i + 1)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - ta)
+        mask0, counts0 = request(0, 1)
+        torch.cuda.synchronize()
+    # one request against the oracle: the reference's own host pipeline on the same photo
+    from PIL import Image
+    im = Image.fromarray(host[0], "RGB").resize((S, S), Image.BILINEAR)
+    xr = torch.from_numpy(np.asarray(im)).permute(2, 0, 1).contiguous().float().div(255)[None]
+    with torch.no_grad():
+        ref = O.forward(xr, {k: torch.from_numpy(v) for k, v in sd_np.items()}, cfg)
+        x_dev = pre.images(photos[0:1])
+        _, lg = model.predict_mask(x_dev, return_logits=True)
+    err = float((lg.cpu() - ref).abs().max())
+    stable = O.mask_stable(ref, 2.0 * err + 1e-7)
+    differ = mask0.cpu().long() != O.predict_mask(ref)
+    lat_ms = np.sort(np.asarray(lat)) * 1e3
+    out = {"workload": f"request path on the device: uint8 photo {H}x{W} (in HBM) -> Resize(({S},{S})) + ToTensor -> ViT-B/16, {C} classes, fp32 "
+                       f"forward + sigmoid/argmax mask -> per-image class statistics vs a 256x256 label map",
+           "images_per_s_batch8": round(thr, 1), "requests_timed": len(lat),
+           "latency_ms_single_image": {"p50": round(float(np.percentile(lat_ms, 50)), 3), "p99": round(float(np.percentile(lat_ms, 99)), 3),
+                                       "min": round(float(lat_ms[0]), 3)},
+           "parity_vs_oracle_one_request": {"input_bit_exact_vs_pillow": bool(torch.equal(x_dev.cpu(), xr)),
+                                            "logits_max_abs_err": err, "mask_mismatch_at_stable_pixels": int((differ & stable).sum()),
+                                            "unstable_pixels": int((~stable).sum())}}
+    del model, photos
+    torch.cuda.empty_cache()
+    return out
+
+
 def collective_name(world):
     """What the process group actually runs its all-reduce on (torch's "nccl" backend IS RCCL on ROCm)."""
     if world <= 1:
@@ -623,6 +740,8 @@ def main():
                     help="skip the configs[2] / configs[4] side runs the default fp32 line appends (train_bf16_path, "
                          "l16_1024_tiled_f16_path)")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode: dropout probability (reference 0.1)")
+    ap.add_argument("--dist-train-batch", type=int, default=64,
+                    help="N > 1: images per rank of the data-parallel training step appended to the line (train_bf16_path)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "prep", "eval"],
                     help="train: one step = forward + CE + backward + gradient all-reduce + Adam (fp32)")
     args = ap.parse_args()
@@ -697,10 +816,21 @@ def main():
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
 
+    split_check = dist_train = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the inference split, seen from every rank: the checksum of each rank's masks (its own shard of the image stream)
+        mine = torch.stack([mask.sum(dtype=torch.int64), torch.tensor(mask.numel(), device=dev)])
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        split_check = {"ranks_seen": dist.get_world_size(), "images_per_rank": B,
+                       "mask_checksum_per_rank": [int(p[0]) for p in parts], "mask_pixels_per_rank": [int(p[1]) for p in parts]}
+        if args.precision == "f32" and not args.no_side_configs:   # the path the north_star shards with a collective
+            logits_keep = logits
+            dist_train = side_train_dist(cfg, sd_np, rank, world, dev, barrier, batch=args.dist_train_batch)
+            logits = logits_keep
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -740,6 +870,10 @@ def main():
             # the HBM-bound pieces against the 8 TB/s roof (algorithmic bytes / hipEvent time, same timed region)
             "roofline_hbm": hbm_rooflines(prof, ("layernorm", "upsample")),
         }
+        if split_check is not None:
+            out["inference_split"] = split_check
+        if dist_train is not None:
+            out["train_bf16_path"] = dist_train
         extras = not args.no_cpu_baseline and world == 1   # CPU baseline / side paths: N = 1 only (spec), rank 0
         if args.precision == "f32" and extras:
             # informational (outside the timed region, rank 0 only): the same step on the other operand formats.
@@ -781,6 +915,7 @@ def main():
             out["train_bf16_path"] = side_train_bf16(cfg, sd_np, x, dev)
             x = None
             out["l16_1024_tiled_f16_path"] = side_l16_tiled_f16(dev)
+            out["serve_path"] = side_serve(dev)
         print(json.dumps(out), flush=True)
     barrier()
     if world > 1:

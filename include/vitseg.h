@@ -319,6 +319,10 @@ int vitseg_eval_counts(const uint8_t* pred, const uint8_t* gt, int n, int S, int
  * step is 1-based; gradients are multiplied by grad_scale first (1/world for summed all-reduce). */
 int vitseg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n_floats, float lr,
                      float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* the same with torch.optim.AdamW's decoupled weight decay (params *= 1 - lr * weight_decay in front of the update): what
+ * PAEDTrainer.configure_optimizers builds (model/PAED/classes.py:536-548, AdamW(lr=1e-4), weight_decay 1e-2 by default) */
+int vitseg_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n_floats, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
 /* fp32 GEMM with explicit operand forms, exported for the parity tests of the backward GEMMs:
  * C[M,N] = A . W with A N-form [M][K] (ta = 0) or T-form [K][M] (ta = 1), W N-form [N][K] (tb = 0) or

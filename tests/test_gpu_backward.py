@@ -268,6 +268,51 @@ def test_fused_adam_matches_torch_adam():
     assert (a.detach().cpu() - p0).abs().max().item() > 1e-5  # it did move
 
 
+def test_fused_adamw_matches_torch_adamw():
+    """vitseg_adamw_step against torch.optim.AdamW(lr=1e-4) -- PAEDTrainer.configure_optimizers, model/PAED/classes.py:536-548
+    (decoupled weight decay, torch's default 1e-2) -- over several steps, and PAEDTrainer really builds the fused one."""
+    from visiontransformer_amd import paed
+    from visiontransformer_amd.optim import FusedAdamW
+    n = 4096 * 5
+    p0 = _rand(n, seed=2, scale=0.1)   # |p| < 0.5: one ulp is 3e-8
+    a = torch.nn.Parameter(p0.clone().to(DEV))
+    b = torch.nn.Parameter(p0.clone().to(DEV))
+    oa, ob = FusedAdamW([a], lr=1e-4), torch.optim.AdamW([b], lr=1e-4)
+    assert oa.param_groups[0]["weight_decay"] == ob.param_groups[0]["weight_decay"] == 1e-2
+    for step in range(4):
+        g = _rand(n, seed=20 + step, scale=10.0 ** (-step)).to(DEV)
+        a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+        assert (a.detach() - b.detach()).abs().max().item() < 1e-7, step   # 1-2 ulp: torch divides by sqrt(bc2), the kernel multiplies by its reciprocal
+    moved = (a.detach().cpu() - p0)
+    assert moved.abs().max().item() > 1e-4
+    # the decay itself: a zero gradient leaves p * (1 - lr wd)^k
+    c = torch.nn.Parameter(p0.clone().to(DEV))
+    oc = FusedAdamW([c], lr=1e-2, weight_decay=0.5)
+    c.grad = torch.zeros_like(c)
+    oc.step()
+    assert torch.allclose(c.detach().cpu(), p0 * (1 - 1e-2 * 0.5), rtol=3e-7, atol=0)   # 2 ulp: the factor is formed in fp32
+    t = paed.PAEDTrainer(1, 16, 192, 1, 3, image_size=96, device=DEV)
+    cfgd = t.configure_optimizers()
+    assert isinstance(cfgd["optimizer"], FusedAdamW) and cfgd["optimizer"].param_groups[0]["lr"] == 1e-4
+    assert isinstance(cfgd["lr_scheduler"]["scheduler"], torch.optim.lr_scheduler.ReduceLROnPlateau)
+
+
+def test_iou_score_from_class_counts_matches_the_reference_formula():
+    """paed.iou_score on the device (one vitseg_eval_counts launch) against the reference's per-class loop
+    (model/PAED/classes.py:430-447) on the CPU."""
+    from visiontransformer_amd import paed
+    g = torch.Generator().manual_seed(5)
+    pred = torch.randint(0, 17, (3, 224, 224), generator=g)
+    tgt = torch.randint(0, 17, (3, 224, 224), generator=g)
+    tgt[0] = pred[0]                     # a perfect image
+    pred[1][pred[1] == 4] = 5            # a class that is never predicted in image 1
+    ref = paed.iou_score(pred, tgt, 17)                       # CPU tensors: the reference loop
+    got = paed.iou_score(pred.to(DEV), tgt.to(DEV), 17)       # device: class counts
+    assert got.is_cuda and abs(float(got) - float(ref)) < 1e-6, (float(got), float(ref))
+
+
 def test_paed_trainer_step_gradients_match_oracle():
     """PAEDTrainer (binary BCE + Dice + |soft-PAED|, model/PAED/classes.py:664-701): the loss tail runs as tensor
     ops on the logits, its gradient reaches the arena through vitseg_backward(grad_logits)."""

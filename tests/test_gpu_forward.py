@@ -258,12 +258,12 @@ def vit_large_full_depth():
     return cfg, sd, x, ref
 
 
-@pytest.mark.parametrize("precision,tol_logits,tol_mask", [("fp32", 1e-3, 0.0), ("fp16", 1e-3, 5e-3), ("bf16", 3e-2, 5e-2)])
+@pytest.mark.parametrize("precision,tol_logits,tol_mask", [("fp32", 1e-3, 0.0), ("fp16", 1e-3, 3e-3), ("bf16", 3e-2, 2e-2)])
 def test_vit_large_full_depth_512(vit_large_full_depth, precision, tol_logits, tol_mask):
     """All 24 layers of ViT-L/16 on the GPU against the fp64 oracle: logits within the north_star's 1e-3 for fp32 (and for
     fp16, the format configs[4] names), 3e-2 for bf16; masks identical wherever the measured logit error cannot flip the
-    decision (`O.mask_stable`, every precision); the mismatch is reported and capped (0.5 % fp16 / 5 % bf16) on a mask
-    that is half class 0, half class 1 with the boundary everywhere (measured round 4: 4 ppm fp32, 0.23 % fp16)."""
+    decision (`O.mask_stable`, every precision); the mismatch is reported and capped at 1.3 x what was measured (0.3 % fp16 / 2 % bf16) on a mask
+    that is half class 0, half class 1 with the boundary everywhere (measured round 4: 4 ppm fp32, 0.23 % fp16, 1.48 % bf16)."""
     cfg, sd, x, ref = vit_large_full_depth
     m = ViTSegmentationModel(2, 16, 1024, 24, 16, image_size=512, precision=precision, device=DEV).eval()
     m.load_state_dict(sd)
@@ -372,6 +372,29 @@ def test_batch_invariance_at_the_headline_size(precision):
         # the accumulations, seen through the bf16 roundings behind them -- far inside the format's own error (3e-2)
         assert (logits_all[5:9] - logits_4).abs().max().item() < 5e-3
         assert float((mask_all[5:9] != mask_4).float().mean()) < 5e-3
+
+
+def test_seventeen_classes_at_the_headline_size():
+    """The reference's real class count (17, model/PAED/classes.py:418) at the headline geometry (512 x 512, batch 32): the
+    decoder tail then writes 17.8 MB of logits per image.  Size-independent properties: (1) an image's logits and mask do not
+    depend on the rest of the batch (bit for bit); (2) the full-resolution logits ARE the ATen-order bilinear upsample of the
+    low-resolution map (torch.equal against the oracle's restatement); (3) the mask is the first-max argmax of ATen's fp32
+    sigmoid of those logits on EVERY pixel."""
+    cfg = ViTSegConfig(17, 16, 768, 2, 12, image_size=512)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=6, head_gain=8.0).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 32, seed=4)).to(DEV)
+    m = ViTSegmentationModel(17, 16, 768, 2, 12, image_size=512, device=DEV).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        mask_all, logits_all = m.predict_mask(x, return_logits=True)
+        low = m.debug_buffer(32, _lib.BUF_LOWRES).view(32, 17, 32, 32)[7:8].cpu()
+        mask_4, logits_4 = m.predict_mask(x[5:9].contiguous(), return_logits=True)
+    assert torch.isfinite(logits_all).all()
+    assert torch.equal(logits_all[5:9], logits_4) and torch.equal(mask_all[5:9], mask_4)
+    assert len(torch.unique(mask_all[7])) >= 5                       # several of the 17 classes win somewhere
+    up = O.upsample_bilinear(low, (512, 512))
+    assert torch.equal(up, logits_all[7:8].cpu())
+    assert torch.equal(O.predict_mask(up).to(torch.uint8), mask_all[7:8].cpu())
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

@@ -36,7 +36,7 @@ EXPORTS = [
     "vitseg_op_wgrad_bf16", "vitseg_op_wgrad_bf16_scratch_floats", "vitseg_op_attention_bwd_bf16", "vitseg_attention_dropmask_bytes", "vitseg_attention_bwd_scratch_floats", "vitseg_op_colsum_scratch_floats",
     "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss", "vitseg_op_linear_f32_ex", "vitseg_resize_nearest_i64",
     "vitseg_small_splits", "vitseg_op_linear_f32_small", "vitseg_op_linear_resln_f32_small", "vitseg_op_attention_f32_small",
-    "vitseg_dbg_linear_f32_small",
+    "vitseg_dbg_linear_f32_small", "vitseg_adamw_step",
 ]
 VERSION = 110   # include/vitseg.h VITSEG_VERSION this binding was written against
 KERNEL_KINDS = ["gemm_bias", "gemm_gelu", "gemm_resadd", "gemm_patch", "gemm_conv3", "attention", "layernorm",
@@ -127,6 +127,7 @@ def lib() -> C.CDLL:
         l.vitseg_eval_counts.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
         l.vitseg_grad_bucket_range.argtypes = [pcfg, i32, psz, psz]
         l.vitseg_adam_step.argtypes = [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, f32, vp]
+        l.vitseg_adamw_step.argtypes = [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, f32, vp]
         l.vitseg_op_gemm_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
         l.vitseg_attention_bwd_scratch_floats.argtypes = [i32, i32, i32]

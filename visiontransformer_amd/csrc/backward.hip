@@ -478,10 +478,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 
 // ---- Adam (torch.optim.Adam defaults, single fused pass over the flat arena) --------------------
 // exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// decay = 1 - lr * weight_decay: torch.optim.AdamW's decoupled weight decay, p.mul_(decay) in front of the update
+// (model/PAED/classes.py:536-548); 1 (an exact multiply) for plain Adam
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, size_t n4, float b1,
                                                    float b2, float eps, float step_size, float inv_bc2_sqrt,
-                                                   float grad_scale) {
+                                                   float grad_scale, float decay) {
+#pragma clang fp contract(off)   // p.mul_(decay) is rounded before the update is subtracted, as torch does it
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
 #pragma unroll
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             mv[e] = mv[e] + (gr - mv[e]) * (1.0f - b1);
             vv[e] = vv[e] * b2 + (1.0f - b2) * gr * gr;
             const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
-            pv[e] = pv[e] - step_size * (mv[e] / denom);
+            pv[e] = pv[e] * decay - step_size * (mv[e] / denom);
         }
         ((f32x4*)p)[i] = pv;
         ((f32x4*)m)[i] = mv;
@@ -756,11 +759,11 @@ int launch_embed_bwd(const float* dX, float* dpos, float* dcls, int B, int Np, i
     return VITSEG_OK;
 }
 int launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step,
-                float grad_scale, hipStream_t s) {
+                float grad_scale, hipStream_t s, float weight_decay) {
     VITSEG_CHECK_ARG(n % 4 == 0 && step >= 1, VITSEG_EINVAL, "adam: n %% 4 != 0 or step < 1");
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, p, g, m, v, n / 4, b1, b2, eps,
-                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, (float)(1.0 - (double)lr * (double)weight_decay));
     VITSEG_LAUNCH_CHECK("adam");
     return VITSEG_OK;
 }

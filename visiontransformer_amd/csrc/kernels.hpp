@@ -165,6 +165,6 @@ int launch_im2col_patch(const float* img, float* T, int B, int Cin, int S, int P
 int launch_conv_dgrad_weight(const float* W0, float* Wd, int D, hipStream_t s);
 int launch_embed_bwd(const float* dX, float* dpos, float* dcls, int B, int Np, int D, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step,
-                float grad_scale, hipStream_t s);
+                float grad_scale, hipStream_t s, float weight_decay = 0.f);
 
 }  // namespace vitseg
