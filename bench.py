@@ -654,7 +654,7 @@ def side_serve(dev, seconds=6.0):
     # one request against the oracle: the reference's own host pipeline on the same photo
     from PIL import Image
     im = Image.fromarray(host[0], "RGB").resize((S, S), Image.BILINEAR)
-    xr = torch.from_numpy(np.asarray(im)).permute(2, 0, 1).contiguous().float().div(255)[None]
+    xr = torch.from_numpy(np.array(im)).permute(2, 0, 1).contiguous().float().div(255)[None]
     with torch.no_grad():
         ref = O.forward(xr, {k: torch.from_numpy(v) for k, v in sd_np.items()}, cfg)
         x_dev = pre.images(photos[0:1])

@@ -24,8 +24,16 @@ def build(g: Golden, precision="fp32"):
     return m
 
 
+@pytest.mark.parametrize("route", ["small", "large"])
 @pytest.mark.parametrize("name", CASES)
-def test_forward_matches_golden(name):
+def test_forward_matches_golden(name, route):
+    """Every golden case through BOTH fp32 routes: the small-batch route vitseg_forward takes below 16 384 token rows
+    (csrc/small.hpp; every golden is that small) and, with the `no_small` switch, the large-batch kernels."""
+    with _lib.option("no_small", int(route == "large")):
+        _forward_matches_golden(name)
+
+
+def _forward_matches_golden(name):
     g = Golden(name)
     m = build(g)
     x = g.images().to(DEV)
@@ -316,9 +324,15 @@ def test_reference_configuration_grid(P, D, A):
 def test_cls_split_k_path_parity_and_batch_invariance(precision):
     """At 512x512 the patch rows fill whole row tiles, so the CLS rows of every linear layer go through the split-K side
     launch (GemmArgs::thin_rows).  Checked against the oracle, and bit for bit across batch sizes: a CLS row takes the
-    same path (same K slices, same summation order) whether it is image 0 of 2 or image 1 of 4.  (Both batches are 2050+
-    token rows: below 2048 rows the fp32 forward takes the small-batch route of csrc/small.hpp, which has its own invariance
-    tests in tests/test_gpu_small.py -- an output's bits are fixed within a route, not across the two.)"""
+    same path (same K slices, same summation order) whether it is image 0 of 2 or image 1 of 4.  (fp32 batches of fewer
+    than 16 384 token rows take the small-batch route of csrc/small.hpp instead -- the `no_small` switch keeps this test on
+    the kernels it is about; that route has its own invariance tests in tests/test_gpu_small.py.  An output's bits are
+    fixed within a route, not across the two.)"""
+    with _lib.option("no_small", 1):
+        _cls_split_k_body(precision)
+
+
+def _cls_split_k_body(precision):
     cfg = ViTSegConfig(2, 16, 192, 2, 3, image_size=512)
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=77).items()}
     x = torch.from_numpy(synth.make_images(cfg, 4, seed=7))
@@ -344,8 +358,8 @@ def test_cls_split_k_path_parity_and_batch_invariance(precision):
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_batch_invariance_at_the_headline_size(precision):
     """BASELINE configs[1] geometry (ViT-B/16, 512 x 512, batch 32), where the oracle would take minutes: a size-independent
-    property instead -- the logits and the mask of an image do not depend on what else is in the batch.  Images 5 .. 8 of
-    a batch of 32 against the same four images as a batch of their own: bit for bit in fp32 (persistent GEMMs, attention and
+    property instead -- the logits and the mask of an image do not depend on what else is in the batch.  Images 5 .. of
+    a batch of 32 against the same images as a batch of their own: bit for bit in fp32 (persistent GEMMs, attention and
     the CLS side path all keep a row's summation order), to fp32-rounding level in bf16."""
     cfg = ViTSegConfig(2, 16, 768, 12, 12, image_size=512)
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=5).items()}
@@ -360,12 +374,15 @@ def test_batch_invariance_at_the_headline_size(precision):
         sd["seg_head.2.bias"][1] += float((lg[:, 0] - lg[:, 1]).median())
         m.load_state_dict(sd)
         mask_all, logits_all = m.predict_mask(x, return_logits=True)
-        mask_4, logits_4 = m.predict_mask(x[5:9].contiguous(), return_logits=True)
+        # fp32: a slice of 16 images = 16 400 token rows, the large-batch route like the batch of 32 (below 16 384 rows the
+        # small-batch route takes over, csrc/small.hpp); 16-bit: 4 images as before
+        lo, hi = (5, 21) if precision == "fp32" else (5, 9)
+        mask_4, logits_4 = m.predict_mask(x[lo:hi].contiguous(), return_logits=True)
     assert torch.isfinite(logits_all).all()
     assert 0.05 < float(mask_all.float().mean()) < 0.95
     if precision == "fp32":   # the headline / parity path: one kernel family and one summation order per row at every batch size
-        assert torch.equal(logits_all[5:9], logits_4)
-        assert torch.equal(mask_all[5:9], mask_4)
+        assert torch.equal(logits_all[lo:hi], logits_4)
+        assert torch.equal(mask_all[lo:hi], mask_4)
     else:
         # 16-bit: the dispatcher picks tile shapes (and lets the CLS rows ride in the persistent kernel's last round or not)
         # by the batch's row count, i.e. MFMA shapes with different internal summation trees: equal up to fp32 rounding of
@@ -388,9 +405,9 @@ def test_seventeen_classes_at_the_headline_size():
     with torch.no_grad():
         mask_all, logits_all = m.predict_mask(x, return_logits=True)
         low = m.debug_buffer(32, _lib.BUF_LOWRES).view(32, 17, 32, 32)[7:8].cpu()
-        mask_4, logits_4 = m.predict_mask(x[5:9].contiguous(), return_logits=True)
+        mask_4, logits_4 = m.predict_mask(x[5:21].contiguous(), return_logits=True)   # 16 400 rows: the same route as 32 images
     assert torch.isfinite(logits_all).all()
-    assert torch.equal(logits_all[5:9], logits_4) and torch.equal(mask_all[5:9], mask_4)
+    assert torch.equal(logits_all[5:21], logits_4) and torch.equal(mask_all[5:21], mask_4)
     assert len(torch.unique(mask_all[7])) >= 5                       # several of the 17 classes win somewhere
     up = O.upsample_bilinear(low, (512, 512))
     assert torch.equal(up, logits_all[7:8].cpu())

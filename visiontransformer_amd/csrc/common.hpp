@@ -35,6 +35,7 @@ enum Opt {
     OPT_NO_MASK2,          // two-class mask-only upsample through the general kernel instead of upsample_mask2_kernel
     OPT_NO_SMALL,          // fp32 forwards of fewer than 2048 token rows on the large-batch kernels instead of the small-batch route (small.hpp)
     OPT_SMALL_VARIANT,     // gemm_f32s tile variant 1..5 for every launch (0: small_plan picks)
+    OPT_SMALL_MAX_ROWS,    // fp32 forwards below this many token rows take the small-batch route (0: the built-in SMALL_MAX_ROWS)
     OPT_COUNT
 };
 long opt(int id);

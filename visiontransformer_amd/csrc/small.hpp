@@ -1,8 +1,12 @@
 // The SMALL-BATCH regime of the fp32 path: fewer than SMALL_MAX_ROWS token rows per forward -- the regime the reference
-// itself runs and publishes in (batch 4 x 224x224: 788 rows; model/CE/datasetTestViTmodel.py:97-109,174-186) and the
-// worker's single-image call (197 rows; model/CE/testViTModel.py:92-126).  At these sizes every GEMM of the large-batch
-// path is a fraction of one round of its 256x128 / 128x128 tiles; the kernels declared here cut the same arithmetic
-// differently (gemm_f32s.hip, rows_small.hip, attention_small.hip) and vitseg_small.hip strings them together.
+// itself runs and publishes in (batch 4 x 224x224: 788 rows at P = 16, 3 140 at P = 8, 12 548 at P = 4;
+// model/CE/datasetTestViTmodel.py:97-109,174-186) and the worker's single-image call (197 rows;
+// model/CE/testViTModel.py:92-126).  At these sizes the GEMMs of the large-batch path are a fraction of one round (or a
+// few ragged rounds) of its 256x128 / 128x128 tiles; the kernels declared here cut the same arithmetic differently
+// (gemm_f32s.hip, rows_small.hip, attention_small.hip) and vitseg_api.hip:forward_small strings them together.
+// Where the boundary sits is a measurement (profiles/r05_ref_grid_threshold.txt): the route wins up to the largest
+// published configuration (12 548 rows: 0.74 of the fp32 peak against 0.72) and loses to the persistent kernel at the
+// headline's 32 800 rows (0.85).
 //
 // Summation order (what makes the results independent of the batch size inside the regime): a linear layer's reduction is
 // cut into small_splits(N, K) chunks -- a function of the layer's shape only, never of M -- each chunk is one fp32 fmaf
@@ -13,7 +17,7 @@
 
 namespace vitseg {
 
-constexpr int SMALL_MAX_ROWS = 2048;
+constexpr int SMALL_MAX_ROWS = 16384;
 
 enum SmallEpi {
     SE_PARTIAL = 0,   // C[s] = chunk sum s (no bias): consumed by resln_kernel / headfin_kernel
@@ -77,7 +81,9 @@ int launch_headfin(const float* partial, size_t split_stride, const float* b0, c
 // softmax(q k^T / 8) v for short sequences: one block per 32 queries of one (image, head), the four waves split the keys
 int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s);
 
-// true when vitseg_forward takes the small-batch route
+// true when vitseg_forward takes the small-batch route (fewer than small_max_rows() token rows: SMALL_MAX_ROWS unless the
+// small_max_rows option says otherwise)
+long small_max_rows();
 bool small_applies(const vitseg_config* cfg, int batch, int precision);
 
 }  // namespace vitseg

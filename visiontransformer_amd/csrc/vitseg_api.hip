@@ -35,7 +35,7 @@ int hip_fail(hipError_t e, const char* what) {
 // ---- dispatcher switches (common.hpp Opt) ----
 static const char* const g_opt_names[OPT_COUNT] = {"no_f32p", "no_p8", "no_h16p", "no_ragged_p8", "no_dropmask",
                                                    "dropw_limit_mb", "upsample_global", "bf16_tiles", "f32p_noinl", "gn", "no_mask2", "no_small",
-                                                   "small_variant"};
+                                                   "small_variant", "small_max_rows"};
 static std::atomic<long> g_opts[OPT_COUNT];
 static int opt_index(const char* name) {
     if (!name) return -1;
@@ -50,7 +50,7 @@ static long opt_parse(int id, const char* text) {
     char* end = nullptr;
     const long v = strtol(text, &end, 10);
     if (end != text) return v;
-    return (id == OPT_DROPW_LIMIT_MB || id == OPT_GN || id == OPT_SMALL_VARIANT || id == OPT_BF16_TILES) ? 0 : 1;
+    return (id == OPT_DROPW_LIMIT_MB || id == OPT_GN || id == OPT_SMALL_VARIANT || id == OPT_SMALL_MAX_ROWS || id == OPT_BF16_TILES) ? 0 : 1;
 }
 static const bool g_opts_loaded = [] {   // once, at library load
     for (int i = 0; i < OPT_COUNT; ++i) {
@@ -102,7 +102,7 @@ Plan make_plan(const Shape& s, int B, int precision) {
         const size_t need = (size_t)whole_split((int)p.Mt, nk[0], nk[1], 32) * p.Mt * nk[0];
         if (need > p.thin_floats) p.thin_floats = need;
     }
-    if (precision == VITSEG_F32 && p.Mt < (size_t)SMALL_MAX_ROWS) {   // K-chunk slabs of the small-batch route (small.hpp)
+    if (precision == VITSEG_F32 && (long)p.Mt < small_max_rows() && !opt(OPT_NO_SMALL)) {   // K-chunk slabs of the small-batch route (small.hpp)
         const size_t need[4] = {(size_t)small_splits(s.D, s.D) * p.Mt * s.D, (size_t)small_splits(s.D, s.I) * p.Mt * s.D,
                                 (size_t)small_splits(s.D, s.Kp) * p.Mt * s.D, (size_t)9 * p.Mp * MID};
         for (size_t n : need)
@@ -147,7 +147,21 @@ int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, c
         return launch_resln(r, st);
     };
     // ---- embeddings (a2 + a3): patch projection chunks, then bias + position embedding + CLS rows + LayerNorm 1 of layer 0
-    {
+    // (patch sizes the gathering DMA does not cover -- P = 4: 48 values per patch -- take the large-batch route's launches)
+    const bool dma_patch = (s.P == 8 || s.P == 16 || s.P == 32) && s.Kp % 32 == 0;
+    if (!dma_patch) {
+        GemmArgs g{};
+        g.A = x; g.W = W(VITSEG_T_PATCH_W); g.bias = W(VITSEG_T_PATCH_B); g.R = W(VITSEG_T_POS); g.C = X;
+        g.M = Mp; g.N = D; g.K = s.Kp; g.lda = 0; g.ldc = D;
+        g.S = s.S; g.P = s.P; g.g = s.g; g.Np = s.Np; g.Cin = s.Cin; g.D = D;
+        {
+            ProfScope ps(VITSEG_K_GEMM_PATCH, 2.0 * g.M * g.N * g.K, st);
+            if ((rc = launch_gemm_f32(g, A_PATCH, EPI_POS, st, 0))) return rc;
+        }
+        if ((rc = launch_cls_rows(W(VITSEG_T_CLS), W(VITSEG_T_POS), X, batch, s.Np, D, st))) return rc;
+        ProfScope ps(VITSEG_K_LAYERNORM, (double)Mt * D * 8, st);
+        if ((rc = launch_layernorm(X, W(VITSEG_T_LN1_W, 0), W(VITSEG_T_LN1_B, 0), H, Mt, D, cfg->layer_norm_eps, 0, st))) return rc;
+    } else {
         SGemm g{};
         g.A = x; g.W = W(VITSEG_T_PATCH_W); g.C = part;
         g.M = Mp; g.N = D; g.K = s.Kp; g.lda = 0; g.ldw = s.Kp; g.ldc = D;
@@ -163,7 +177,13 @@ int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, c
         if ((rc = linear(H, Mt, D, D, VITSEG_T_WQKV, VITSEG_T_BQKV, l, QKV, 3 * D, SE_BIAS, VITSEG_K_GEMM_BIAS))) return rc;
         {
             ProfScope ps(VITSEG_K_ATTENTION, 4.0 * batch * s.A * (double)s.N * s.N * 64, st);
-            if ((rc = launch_attention_small(QKV, H, batch, s.Np, s.A, st))) return rc;
+            // by the SHAPE only (a row's bits must not depend on the batch): patch counts that are whole 64-key tiles and long
+            // enough to fill 128-query blocks (512x512: 1024) take attention_f32's tail-free loop, every other length the
+            // key-split kernel (tools/attn_small_probe.py, profiles/r05_attn_small_probe.txt: 197 and 785 tokens 1.1-2.7x
+            // faster at every batch; 1025 tokens faster only at batch 1)
+            rc = (s.Np % 64 == 0 && s.N > 400) ? launch_attention_f32(QKV, H, nullptr, batch, s.Np, s.A, DropArgs{}, st)
+                                                : launch_attention_small(QKV, H, batch, s.Np, s.A, st);
+            if (rc) return rc;
         }
         if ((rc = linear(H, Mt, D, D, VITSEG_T_WO, VITSEG_T_BO, l, part, D, SE_PARTIAL, VITSEG_K_GEMM_RESADD))) return rc;
         if ((rc = rows(small_splits(D, D), W(VITSEG_T_BO, l), W(VITSEG_T_LN2_W, l), W(VITSEG_T_LN2_B, l), Mt, false))) return rc;
@@ -201,12 +221,16 @@ Profiler& profiler() {
     return p;
 }
 
+long small_max_rows() {
+    const long v = opt(OPT_SMALL_MAX_ROWS);
+    return v > 0 ? v : SMALL_MAX_ROWS;
+}
+
 bool small_applies(const vitseg_config* cfg, int batch, int precision) {
     Shape s;
     if (precision != VITSEG_F32 || opt(OPT_NO_SMALL) || check_config(cfg, &s)) return false;
     const long rows = (long)batch * s.N;
-    return rows < SMALL_MAX_ROWS && (s.P == 8 || s.P == 16 || s.P == 32) && s.D % 64 == 0 && s.I % 32 == 0 && s.I > s.D &&
-           s.Kp % 32 == 0 && s.S % 4 == 0;
+    return rows < small_max_rows() && s.D % 64 == 0 && s.I % 32 == 0 && s.I > s.D && s.S % 4 == 0;
 }
 }  // namespace vitseg
 
