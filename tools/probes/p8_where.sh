@@ -85,6 +85,13 @@ w("noepi_nodma_clock", clocked(nodma))
 w("noepi_noread_clock", clocked(noread))
 w("noepi_noread_nodma_clock", clocked(strip_dma(noread)))
 w("noepi_nobarrier_clock", clocked(nobar))
+# round 5, VERDICT item 2 (iii): ONE barrier per phase instead of two (the barrier behind each MFMA quadrant is gone; the wave
+# rows then run a whole phase apart instead of half a phase; the vmcnt margins are one phase short, so the tiles race: timing
+# only).  Between the product (8 barriers per K step) and noepi_nobarrier (none).
+import re
+onebar, n_onebar = re.subn(r"(mfma_quad\(\d, \d, w\d\);\s*\\\n\s*)P8_BAR\(\);", r"\1;        ", noepi)
+assert n_onebar == 4, n_onebar
+w("noepi_onebar_clock", clocked(onebar))
 # the cursors never move (every K step streams the same rows): the scalar work of advance() is gone
 noadv = rep(noepi, "        advance(cur0);                                                                               \\\n        advance(cur1);                                                                               \\\n", "")
 w("noepi_noadvance_clock", clocked(noadv))

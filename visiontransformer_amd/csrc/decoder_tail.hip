@@ -455,7 +455,14 @@ int launch_upsample(const float* Z, float* logits, uint8_t* mask, int B, int C, 
     // 2 bands = 256 threads; S = 224: 4 bands = 224 threads) -- and the source rows of its output rows must fit the LDS
     int bpb = quads <= 256 ? 256 / quads : 0;
     while (bpb > 1 && bands % bpb) --bpb;
-    const bool whole = bpb >= 1 && quads * bpb >= 128;
+    // few images: smaller blocks rather than a grid of a few dozen (one 224x224 image: 14 blocks of 4 bands took 18 us)
+    while (bpb > 1 && (long)B * bands / bpb < 2 * device_num_cus()) {
+        int nb = bpb - 1;
+        while (nb > 1 && bands % nb) --nb;
+        if (quads * nb < 48) break;
+        bpb = nb;
+    }
+    const bool whole = bpb >= 1 && quads * bpb >= 48;
     const int threads = whole ? quads * bpb : 256;
     const int rows_out = whole ? bpb * UPR : 0;
     const size_t nr_max = (size_t)((double)rows_out * g / S) + 3;

@@ -194,6 +194,14 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][nt][e], fa[slot][mt][e], acc[mt][nt], 0, 0, 0);
     };
 
+    // Direct epilogues (one K chunk per launch) sum the reduction in p.kh equal pieces -- acc is folded into `sum` and
+    // restarted from zero every KT / kh steps: result = ((h0 + h1) + h2) + h3 -- because the one-image kernel below
+    // (gemm_f32s_kw_kernel) computes the pieces on four waves at once, and a row's bits must not depend on which kernel ran.
+    constexpr bool FOLD = EPI != SE_PARTIAL;
+    f32x16 sum[FOLD ? MT : 1][FOLD ? NT : 1];
+    const int KC = FOLD && p.kh > 1 ? KT / p.kh : KT;
+    int kc_left = KC;
+    bool folded = false;
     __builtin_amdgcn_s_barrier();   // B0
     __builtin_amdgcn_sched_barrier(0);
     read_frags(0, 0, 0);
@@ -218,6 +226,29 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
         }
         mfma_group(1);
         st = nst;
+        if constexpr (FOLD) {
+            if (--kc_left == 0 && KC != KT) {   // a piece is complete
+                kc_left = KC;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            sum[mt][nt][r] = folded ? sum[mt][nt][r] + acc[mt][nt][r] : acc[mt][nt][r];
+                            acc[mt][nt][r] = 0.f;
+                        }
+                folded = true;
+            }
+        }
+    }
+    if constexpr (FOLD) {
+        if (folded) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = sum[mt][nt];
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -263,9 +294,177 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
     }
 }
 
+
+// ---- one image: the four K pieces of a direct-epilogue GEMM on four waves --------------------------------------------
+// At 197 rows a wave of gemm_f32s_kernel owns one 32 x 32 tile over the WHOLE reduction: 24 dependent K steps = 12 us, with
+// half the CUs idle (7 x 18 tiles of 32 x 128).  Only cutting K shortens that chain.  Here a block is one 32 x (32 NT) output
+// tile and its four compute waves each run ONE piece of the reduction (K / 4: 6 steps at K = 768) on all NT sub-tiles; the
+// loader wave streams the four pieces side by side (a ring stage = 4 x (32 + 32 NT) operand rows); the pieces are parked in
+// LDS and added in piece order ((h0 + h1) + h2) + h3 -- exactly what gemm_f32s_kernel's FOLD computes one piece after the
+// other, so the two kernels give the same bits and small_plan may pick either by M.
+template <int NT, int EPI>
+__global__ __launch_bounds__(320) void gemm_f32s_kw_kernel(const SGemm p) {
+    constexpr int BN = 32 * NT, CHROWS = 32 + BN;
+    constexpr int STAGE = 4 * CHROWS * 128;
+    constexpr int NSTAGE = 163840 / STAGE >= 3 ? 3 : 2;
+    constexpr int PPC = CHROWS / 8, PIECES = 4 * PPC;   // 1 KiB DMA pieces per K piece / per ring stage
+    constexpr int WAITN = PIECES < 63 ? PIECES : 63;     // (vmcnt is 6 bits; in-order retirement makes 63 a safe stand-in for 64)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3 = K piece, 4 = the loader
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = t % p.tiles_m, tn = t / p.tiles_m;
+    const int m0 = tm * 32, n0 = tn * BN;
+    const int KC = p.K / 128;                                    // K steps per piece
+    auto make_rsrc = [](const void* base, long long bytes) {
+        const unsigned long long b = (unsigned long long)base;
+        i32x4 r;
+        r[0] = (int)(unsigned)b;
+        r[1] = (int)(unsigned)((b >> 32) & 0xffffu);
+        r[2] = (int)(unsigned)(bytes <= 0 ? 0 : (bytes < 0x7fffffffll ? bytes : 0x7fffffffll));
+        r[3] = 0x00020000;
+        return r;
+    };
+    const i32x4 ra = make_rsrc(p.A + (size_t)m0 * p.lda, (long long)(p.M - m0) * p.lda * 4);
+    const i32x4 rw = make_rsrc(p.W + (size_t)n0 * p.ldw, (long long)(p.N - n0) * p.ldw * 4);
+    // barriers (all five waves): B0, B(kt + 1) for kt = 0 .. KC - 2, "ring free", "pieces parked"
+    if (wave == 4) {
+        unsigned voff[PPC];
+#pragma unroll
+        for (int q = 0; q < PPC; ++q) {
+            const int row = 8 * q + (lane >> 3), pos = lane & 7;
+            if (q < 4) voff[q] = (unsigned)row * (unsigned)p.lda * 4u + (unsigned)((pos ^ ((row >> 1) & 7)) * 16);
+            else voff[q] = (unsigned)(row - 32) * (unsigned)p.ldw * 4u + (unsigned)((pos ^ (((row - 32) >> 1) & 7)) * 16);
+        }
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+        auto dma_step = [&](int kt) {
+            const unsigned sb = lds_base + (unsigned)((kt % NSTAGE) * STAGE);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned so = (unsigned)((c * KC + kt) * 32) * 4u;
+#pragma unroll
+                for (int q = 0; q < PPC; ++q) {
+                    if (q < 4)
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                                     :: "s"(sb + (unsigned)((c * PPC + q) * 1024)), "v"(voff[q]), "s"(ra), "s"(so) : "memory");
+                    else
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                                     :: "s"(sb + (unsigned)((c * PPC + q) * 1024)), "v"(voff[q]), "s"(rw), "s"(so) : "memory");
+                }
+            }
+        };
+        auto wait_landed = [&](int ahead) {
+            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        int issued = 0;
+        for (; issued < NSTAGE - 1 && issued < KC; ++issued) dma_step(issued);
+        wait_landed(issued - 1);
+        __builtin_amdgcn_s_barrier();   // B0
+        for (int kt = 0; kt + 1 < KC; ++kt) {
+            if (issued < KC) dma_step(issued++);
+            wait_landed(issued - 1 - (kt + 1));
+            __builtin_amdgcn_s_barrier();   // B(kt + 1)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // the ring is free
+        __builtin_amdgcn_s_barrier();   // the pieces are parked
+        return;
+    }
+    const int li = lane & 31, lh = lane >> 5;
+    const int sw = (li >> 1) & 7;
+    int offj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offj[j] = wave * CHROWS * 128 + li * 128 + (((2 * j + lh) ^ sw) << 4);
+    f32x4 fa[2], fw[2][NT];
+    auto read_frags = [&](int stage, int j, int slot) {
+        const int ab = stage * STAGE + offj[j];
+        fa[slot] = *(const f32x4*)(lds + ab);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fw[slot][nt] = *(const f32x4*)(lds + ab + 4096 + nt * 4096);
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    auto mfma_group = [&](int slot) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][nt][e], fa[slot][e], acc[nt], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_barrier();   // B0
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(0, 0, 0);
+    int st = 0;
+    for (int kt = 0; kt < KC; ++kt) {
+        const int nst = st + 1 == NSTAGE ? 0 : st + 1;
+        read_frags(st, 1, 1);
+        mfma_group(0);
+        read_frags(st, 2, 0);
+        mfma_group(1);
+        read_frags(st, 3, 1);
+        mfma_group(0);
+        if (kt + 1 < KC) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // B(kt + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(nst, 0, 0);
+        }
+        mfma_group(1);
+        st = nst;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the ring is free: piece w parks sub-tile nt in slab 4 nt + w
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float* slab = (float*)(lds + (4 * nt + wave) * 4096);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(f32x4*)(slab + li * 32 + (((2 * q + lh) ^ (li & 7)) << 2)) = f32x4{acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the pieces are parked
+    if (wave >= NT) return;
+    // wave nt finishes sub-tile nt: rows 8 ps + rrow, columns 4 c8 .. + 3 of the four pieces, added in piece order
+    const int nt = wave, rrow = lane >> 3, c8 = lane & 7;
+    const int gcol = n0 + nt * 32 + c8 * 4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (gcol < p.N) bias4 = *(const f32x4*)(p.bias + gcol);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = 8 * ps + rrow;
+        const int o = row * 32 + ((c8 ^ (row & 7)) << 2);
+        f32x4 v = *(const f32x4*)((const float*)(lds + (4 * nt) * 4096) + o);
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            const f32x4 h = *(const f32x4*)((const float*)(lds + (4 * nt + c) * 4096) + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] + h[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] + bias4[e];
+            if (EPI == SE_GELU) x = gelu_erf(x);
+            v[e] = x;
+        }
+        const int grow = m0 + row;
+        if (grow < p.M && gcol < p.N) *(f32x4*)(p.C + (size_t)grow * p.ldc + gcol) = v;
+    }
+}
+
 // Least work on the busiest CU: a block's time is its MFMA stream (KT x MT x NT x 16 MFMAs of 64 cycles on each wave's
 // SIMD) plus a fixed prologue / epilogue; co-resident blocks share the matrix pipes, so their streams add up.
-int small_plan(const SGemm& a, int kc, int amode) {
+constexpr int KW_FIRST = NVARIANTS;   // variant ids NVARIANTS (32 x 64) and NVARIANTS + 1 (32 x 96): gemm_f32s_kw_kernel
+bool kw_applies(const SGemm& a, int epi, int amode, int nt) {
+    return epi != SE_PARTIAL && amode == SA_PLAIN && a.kh == 4 && a.K % 128 == 0 && a.N % (32 * nt) == 0;
+}
+int small_plan(const SGemm& a, int kc, int epi, int amode) {
     const int ncu = device_num_cus();
     double best = 1e30;
     int bv = 0;
@@ -285,8 +484,34 @@ int small_plan(const SGemm& a, int kc, int amode) {
             bv = v;
         }
     }
-    (void)amode;
+    for (int nt = 2; nt <= 3; ++nt) {   // the one-image kernel: a quarter of the K steps per wave, one block per CU
+        if (!kw_applies(a, epi, amode, nt)) continue;
+        const long blocks = (long)((a.M + 31) / 32) * (a.N / (32 * nt));
+        const long per_cu = (blocks + ncu - 1) / ncu;
+        const double time = per_cu * ((double)(a.K / 128) * (nt * 1024 + 200) + 7200.0 + 1600.0 * nt);
+        if (time < best) {
+            best = time;
+            bv = KW_FIRST + nt - 2;
+        }
+    }
     return bv;
+}
+
+template <int NT, int EPI>
+int launch_kw(const SGemm& a, hipStream_t s) {
+    int dev = 0;
+    static bool attr_set[64] = {};
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32s_kw_kernel<NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_f32s_kw)");
+        attr_set[dev] = true;
+    }
+    constexpr int STAGE = 4 * (32 + 32 * NT) * 128;
+    constexpr int LDS = (163840 / STAGE >= 3 ? 3 : 2) * STAGE;
+    hipLaunchKernelGGL((gemm_f32s_kw_kernel<NT, EPI>), dim3(a.tiles_m * a.tiles_n), dim3(320), LDS, s, a);
+    VITSEG_LAUNCH_CHECK("gemm_f32s_kw");
+    return VITSEG_OK;
 }
 
 template <int V, int EPI, int AMODE>
@@ -329,8 +554,17 @@ int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s) {
     VITSEG_CHECK_ARG(amode != SA_PATCH || ((a.P == 8 || a.P == 16 || a.P == 32) && a.S % 4 == 0), VITSEG_ESHAPE, "gemm_f32s: patch size %d", a.P);
     VITSEG_CHECK_ARG((size_t)(a.M + 128) * a.lda * 4 < 0x7fffffffull && (size_t)a.N * a.ldw * 4 < 0x7fffffffull, VITSEG_ESHAPE,
                      "gemm_f32s: operand beyond one buffer descriptor");
-    const long env = opt(OPT_SMALL_VARIANT);
-    a.variant = env > 0 && env <= NVARIANTS ? (int)env - 1 : small_plan(a, kc, amode);
+    a.kh = epi == SE_PARTIAL ? 1 : small_pieces(a.K);
+    const long env = opt(OPT_SMALL_VARIANT);   // 1..5: a tile variant of gemm_f32s_kernel; 6, 7: the one-image kernel (where it applies)
+    a.variant = env > 0 && env <= NVARIANTS + 2 ? (int)env - 1 : small_plan(a, kc, epi, amode);
+    if (a.variant >= KW_FIRST && !kw_applies(a, epi, amode, a.variant - KW_FIRST + 2)) a.variant = small_plan(a, kc, epi, amode);
+    if (a.variant >= KW_FIRST) {
+        const int nt = a.variant - KW_FIRST + 2;
+        a.tiles_m = (a.M + 31) / 32;
+        a.tiles_n = a.N / (32 * nt);
+        if (nt == 2) return epi == SE_GELU ? launch_kw<2, SE_GELU>(a, s) : launch_kw<2, SE_BIAS>(a, s);
+        return epi == SE_GELU ? launch_kw<3, SE_GELU>(a, s) : launch_kw<3, SE_BIAS>(a, s);
+    }
     a.tiles_m = (a.M + VARIANTS[a.variant].bm() - 1) / VARIANTS[a.variant].bm();
     a.tiles_n = (a.N + VARIANTS[a.variant].bn() - 1) / VARIANTS[a.variant].bn();
     if (amode == SA_CONV3) return launch_variant<SE_PARTIAL, SA_CONV3>(a, s);

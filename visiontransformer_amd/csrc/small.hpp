@@ -40,6 +40,7 @@ struct SGemm {
     int splits;          // chunks of K / splits values each (conv3: 9 taps)
     size_t split_stride; // floats
     int tiles_m, tiles_n, variant;   // filled by the launcher (small_plan)
+    int kh;                          // direct epilogues: equal pieces the reduction is summed in (small_pieces(K)); filled by the launcher
     int g, Np, S, P, Cin;            // geometry of SA_CONV3 / SA_PATCH
     // diagnostics (tools/small_stamps.py; null in the product path): 8 words per block -- s_memrealtime at entry and exit,
     // s_memtime at entry / after the prologue / after the K loop / at exit, HW_ID, XCC_ID
@@ -53,6 +54,9 @@ inline int small_splits(int N, int K) {
     const int chunk = K <= 1024 ? 256 : 512;   // o_proj (K = D): D / 256 chunks; fc2 (K = 3072): 6 chunks
     return K % chunk == 0 && K > chunk ? K / chunk : 1;
 }
+// pieces of a direct-epilogue reduction (one chunk): out = ((h0 + h1) + h2) + h3 + bias, h_i = the fmaf chain over the i-th
+// quarter of K -- a shape-only rule like small_splits (the one-image kernel computes the quarters on four waves at once)
+inline int small_pieces(int K) { return K % 128 == 0 ? 4 : (K % 64 == 0 ? 2 : 1); }
 int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s);
 
 // Rows kernel between the GEMMs: x = residual + (sum of the chunk slabs in order + bias), LayerNorm of the new row.
