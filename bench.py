@@ -420,6 +420,23 @@ def bench_ref_grid(args, rank, world, dev, barrier):
                 cpu_budget -= time.perf_counter() - t0
                 e["cpu_baseline"], e["parity"] = base, parity
             entry[f"batch{B}"] = e
+        if cid == 0 and not args.no_side_configs:
+            # the reference's TRAINING regime (model/CE/trainCurrentViTmodel.py:57: batch 4, 224x224; classes.py:264-297): one
+            # step = forward + CE + backward + Adam(lr=1e-5), dropout 0.1 -- informational (these launches are the large-batch
+            # kernels; the small-batch route of section 3b is inference-only so far)
+            del model
+            torch.cuda.empty_cache()
+            y4 = torch.from_numpy(synth.make_targets(cfg, 4, seed=0, first_image=0, size=224)).to(dev)
+            x4 = torch.from_numpy(synth.make_images(cfg, 4, seed=0, first_image=0)).to(dev)
+            entry["train_step_batch4"] = {}
+            for tp in ("fp32", "bf16"):
+                mt = ViTSegmentationModel(17, P, D, L, A, image_size=224, device=dev, precision=tp, dropout=0.1)
+                mt.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+                el, _, loss = run_train_steps(mt, x4, y4, 1, 20, 3, 0, lambda: None)
+                entry["train_step_batch4"][tp] = {"ms_per_step": round(el / 20 * 1e3, 3), "images_per_s": round(4 * 20 / el, 1),
+                                                  "final_loss": float(loss.detach())}
+                del mt
+            model = None
         grid.append(entry)
         del model
         torch.cuda.empty_cache()

@@ -33,18 +33,19 @@ __global__ __launch_bounds__(256) void resln_kernel(const SRows p) {
         bv[i] = ((const f32x4*)p.lnb)[c];
     }
     if (!cls_row) {
-        // the remaining slabs four at a time, their loads in flight together (a dependent round trip per slab made this
-        // kernel 8 us at 788 rows), added in slab order
-        for (int s0 = 1; s0 < p.splits; s0 += 4) {
-            f32x4 t[4][NV];
+        // the remaining slabs five at a time (fc2's six chunks: one group), their loads in flight together with the row's
+        // other loads (a dependent round trip per slab made this kernel 8 us at 788 rows), added in slab order
+        constexpr int G = NV <= 4 ? 5 : 2;
+        for (int s0 = 1; s0 < p.splits; s0 += G) {
+            f32x4 t[G][NV];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < G; ++u) {
                 const f32x4* ps = (const f32x4*)(p.partial + (size_t)min(s0 + u, p.splits - 1) * p.split_stride + (size_t)row * p.D);
 #pragma unroll
                 for (int i = 0; i < NV; ++i) t[u][i] = ps[min(lane + 64 * i, nv - 1)];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < G; ++u) {
                 if (s0 + u < p.splits) {
 #pragma unroll
                     for (int i = 0; i < NV; ++i)
