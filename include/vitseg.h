@@ -172,6 +172,12 @@ int vitseg_op_linear_f32_small(const float* A, const float* W, const float* bias
 int vitseg_op_linear_resln_f32_small(const float* A, const float* W, const float* bias, float* X, const float* lnw,
                                      const float* lnb, float* H, float* scratch, size_t scratch_floats, int M, int N, int K,
                                      float eps, void* stream);
+/* the activation gradient of a linear layer as the small-batch training step computes it (the reference trains at batch 4 x
+ * 224x224, model/CE/trainCurrentViTmodel.py:57):  dX[M, Kd] = dY[M, Nd] . W[Nd, Kd]  with the nn.Linear weight read as it lies
+ * (the reduction runs down its rows).  epilogue 0: plain (K-chunk slabs in `scratch`, >= vitseg_small_splits(Kd, Nd) * M * Kd
+ * floats, summed in chunk order); epilogue 5: dX *= gelu'(R) with R[M, Kd] the saved pre-activation (the wide form). */
+int vitseg_op_dgrad_f32_small(const float* dY, const float* W, const float* R, float* dX, float* scratch, size_t scratch_floats,
+                              int M, int Nd, int Kd, int epilogue, void* stream);
 /* diagnostics: vitseg_op_linear_f32_small with per-block time stamps written by the kernel (8 words per block: s_memrealtime
  * at entry / exit, s_memtime at entry / after the prologue / after the K loop / at exit, HW_ID, XCC_ID; `stamps` must hold
  * 8 words per launched block) and `lds_pad` extra bytes of LDS per block (limits the blocks per CU).  tools/small_stamps.py. */

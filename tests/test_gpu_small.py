@@ -103,6 +103,31 @@ def test_linear_small_rows_do_not_depend_on_the_batch(N, K, epi):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+# activation gradients of the four linears of ViT-B/16 at the reference's training batch (788 rows) and of Tiny/16
+@pytest.mark.parametrize("M,Nd,Kd,epi", [(788, 768, 768, 0), (788, 2304, 768, 0), (788, 3072, 768, 0), (788, 768, 3072, 5),
+                                         (197, 192, 3072, 5), (788, 576, 192, 0), (33, 192, 192, 0)])
+def test_dgrad_small_t_form(M, Nd, Kd, epi):
+    """dX = dY . W (W[Nd, Kd] as nn.Linear stores it; optionally x gelu'(R)) against fp64, identical from every tile variant."""
+    dY, W = _rand(M, Nd, seed=M + 1).to(DEV), _rand(Nd, Kd, seed=Nd + 2, scale=0.05).to(DEV)
+    R = _rand(M, Kd, seed=5, scale=1.5).to(DEV)
+    ref = dY.double() @ W.double()
+    if epi == 5:
+        u = R.double()
+        ref = ref * (0.5 * (1 + torch.erf(u / 2 ** 0.5)) + u * torch.exp(-0.5 * u * u) / (2 * torch.pi) ** 0.5)
+    S = _lib.lib().vitseg_small_splits(Kd, Nd)
+    outs = []
+    for v in range(0, NVARIANTS + 1):
+        scratch = torch.full((max(S, 1) * M * Kd,), float("nan"), device=DEV)
+        dX = torch.full((M, Kd), float("nan"), device=DEV)
+        with _lib.option("small_variant", v):
+            _lib.check(_lib.lib().vitseg_op_dgrad_f32_small(dY.data_ptr(), W.data_ptr(), R.data_ptr(), dX.data_ptr(), scratch.data_ptr(),
+                                                            scratch.numel(), M, Nd, Kd, epi, _stream()))
+        outs.append(dX)
+    assert (outs[0].double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def _attention_ref(qkv, B, Np, A):
     """fp64 softmax(q k^T / 8) v on the patches-first row layout (patch token t of image b in row b Np + t, CLS in row B Np + b)."""
     D = 64 * A

@@ -75,10 +75,12 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
         r[3] = 0x00020000;
         return r;
     };
-    const i32x4 ra = AMODE == SA_PLAIN ? make_rsrc(p.A + (size_t)m0 * p.lda, (long long)(p.M - m0) * p.lda * 4)
+    const i32x4 ra = AMODE == SA_PLAIN || AMODE == SA_PLAIN_WT ? make_rsrc(p.A + (size_t)m0 * p.lda, (long long)(p.M - m0) * p.lda * 4)
                      : AMODE == SA_CONV3 ? make_rsrc(p.A, (long long)p.M * p.lda * 4)
                                          : make_rsrc(p.A, (long long)(p.M / p.Np) * p.Cin * p.S * p.S * 4);
-    const i32x4 rw = make_rsrc(p.W + (size_t)n0 * p.ldw, (long long)(p.N - n0) * p.ldw * 4);
+    constexpr bool WT = AMODE == SA_PLAIN_WT;   // W[k][n] (n contiguous): the stage's W region is [32 k][BN n]
+    const i32x4 rw = WT ? make_rsrc(p.W + n0, ((long long)p.K * p.ldw - n0) * 4)
+                        : make_rsrc(p.W + (size_t)n0 * p.ldw, (long long)(p.N - n0) * p.ldw * 4);
 
     // Barrier protocol (all five waves): B0 = K step 0 has landed; B(kt + 1), kt = 0 .. KT - 2 = step kt + 1 has landed AND
     // every compute wave holds its last fragments of step kt (its ring stage is free); one more after the loop (the ring is
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
             const int row = 8 * q + (lane >> 3), pos = lane & 7;
             if (q < BM / 8) {
                 const int chunk = pos ^ ((row >> 1) & 7);
-                if (AMODE == SA_PLAIN) {
+                if (AMODE == SA_PLAIN || AMODE == SA_PLAIN_WT) {
                     voff[q] = (unsigned)row * (unsigned)p.lda * 4u + (unsigned)(chunk * 16);
                 } else if (AMODE == SA_CONV3) {
                     const int r = m0 + row;
@@ -115,6 +117,11 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
                     const int e4 = 4 * chunk;
                     voff[q] = r < p.M ? (unsigned)(((b * p.Cin) * p.S + gy * p.P + e4 / p.P) * p.S + gx * p.P + e4 % p.P) * 4u : OOB;
                 }
+            } else if (WT) {
+                // T-form: piece = 1 KiB of the [32 k][BN n] region in order (k row = BN * 4 bytes; a column group beyond N reads the
+                // next k row's values: those columns are computed and never stored)
+                const unsigned off = (unsigned)((q - BM / 8) * 1024 + 16 * lane);
+                voff[q] = (off / (BN * 4)) * (unsigned)p.ldw * 4u + off % (BN * 4);
             } else {
                 const int wrow = row - BM;
                 voff[q] = (unsigned)wrow * (unsigned)p.ldw * 4u + (unsigned)((pos ^ ((wrow >> 1) & 7)) * 16);
@@ -123,14 +130,14 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
         const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
         // scalar byte offsets of K step kt: W columns k0w + 32 kt; A by mode
         auto soff_a = [&](int kt) -> unsigned {
-            if (AMODE == SA_PLAIN) return (unsigned)(k0w + 32 * kt) * 4u;
+            if (AMODE == SA_PLAIN || AMODE == SA_PLAIN_WT) return (unsigned)(k0w + 32 * kt) * 4u;
             if (AMODE == SA_CONV3) return (unsigned)(32 * kt) * 4u;
             const int k = k0w + 32 * kt, pp = p.P * p.P;      // patch: k = (c, py, px); 32 | P^2 and P | 32 kt (P = 8, 16, 32)
             return (unsigned)((k / pp) * p.S * p.S + ((k % pp) / p.P) * p.S) * 4u;
         };
         auto dma_step = [&](int kt) {   // K step kt into ring stage kt % NSTAGE
             const unsigned sb = lds_base + (unsigned)((kt % NSTAGE) * STAGE);
-            const unsigned sa = soff_a(kt), sw_ = (unsigned)(k0w + 32 * kt) * 4u;
+            const unsigned sa = soff_a(kt), sw_ = WT ? (unsigned)(k0w + 32 * kt) * (unsigned)p.ldw * 4u : (unsigned)(k0w + 32 * kt) * 4u;
 #pragma unroll
             for (int q = 0; q < PIECES; ++q) {
                 if (q < BM / 8)
@@ -174,8 +181,15 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
         const int wb = stage * STAGE + BM * 128 + wc * NT * 4096 + offj[j];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fa[slot][mt] = *(const f32x4*)(lds + ab + mt * 4096);
+        if (WT) {   // [k][n] region: lane (li, lh) gathers k = 8 j + 4 lh + e, n = its column -- four conflict-free 4-byte reads
+            const float* wr_ = (const float*)(lds + stage * STAGE + BM * 128) + (8 * j + 4 * lh) * BN + wc * NT * 32 + li;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) fw[slot][nt] = *(const f32x4*)(lds + wb + nt * 4096);
+            for (int nt = 0; nt < NT; ++nt)
+                fw[slot][nt] = f32x4{wr_[nt * 32], wr_[BN + nt * 32], wr_[2 * BN + nt * 32], wr_[3 * BN + nt * 32]};
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fw[slot][nt] = *(const f32x4*)(lds + wb + nt * 4096);
+        }
     };
     f32x16 acc[MT][NT];   // acc[mt][nt][r] = C[m = 32 mt + li][n = 32 nt + (r & 3) + 8 (r >> 2) + 4 lh]
 #pragma unroll
@@ -270,21 +284,30 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
                 *(f32x4*)(slab + li * 32 + (((2 * q + lh) ^ (li & 7)) << 2)) = f32x4{tl[4 * q], tl[4 * q + 1], tl[4 * q + 2], tl[4 * q + 3]};
             const int gcol = n0 + (wc * NT + nt) * 32 + c8 * 4;
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-            if (EPI != SE_PARTIAL && gcol < p.N) bias4 = *(const f32x4*)(p.bias + gcol);
+            if ((EPI == SE_BIAS || EPI == SE_GELU) && gcol < p.N) bias4 = *(const f32x4*)(p.bias + gcol);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int row = 8 * ps + rrow;
                 f32x4 v = *(const f32x4*)(slab + row * 32 + ((c8 ^ (row & 7)) << 2));
                 const int grow = m0 + (wr * MT + mt) * 32 + row;
-                if (EPI != SE_PARTIAL) {
+                const bool live = grow < p.M && gcol < p.N;
+                const size_t o = (size_t)grow * p.ldc + gcol;
+                if (EPI == SE_BIAS || EPI == SE_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = v[e] + bias4[e];
-                        if (EPI == SE_GELU) x = gelu_erf(x);
-                        v[e] = x;
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] + bias4[e];
+                    if (EPI == SE_GELU) {
+                        if (p.aux && live) *(f32x4*)(p.aux + o) = v;   // the pre-activation, saved for the backward
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                     }
                 }
-                if (grow < p.M && gcol < p.N) *(f32x4*)(cbase + (size_t)grow * p.ldc + gcol) = v;
+                if (EPI == SE_DGELU) {
+                    f32x4 u = {0.f, 0.f, 0.f, 0.f};
+                    if (live) u = *(const f32x4*)(p.R + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf_grad(u[e]);
+                }
+                if (live) *(f32x4*)(cbase + o) = v;
             }
         }
     if (stamp) {
@@ -447,14 +470,16 @@ __global__ __launch_bounds__(320) void gemm_f32s_kw_kernel(const SGemm p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] + h[e];
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = v[e] + bias4[e];
-            if (EPI == SE_GELU) x = gelu_erf(x);
-            v[e] = x;
-        }
         const int grow = m0 + row;
-        if (grow < p.M && gcol < p.N) *(f32x4*)(p.C + (size_t)grow * p.ldc + gcol) = v;
+        const bool live = grow < p.M && gcol < p.N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] + bias4[e];
+        if (EPI == SE_GELU) {
+            if (p.aux && live) *(f32x4*)(p.aux + (size_t)grow * p.ldc + gcol) = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (live) *(f32x4*)(p.C + (size_t)grow * p.ldc + gcol) = v;
     }
 }
 
@@ -547,12 +572,14 @@ int launch_variant(const SGemm& a, hipStream_t s) {
 
 int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s) {
     VITSEG_CHECK_ARG(a.A && a.W && a.C && a.M > 0 && a.N > 0 && a.K > 0 && a.splits >= 1, VITSEG_EINVAL, "gemm_f32s: bad arguments");
-    VITSEG_CHECK_ARG(epi == SE_PARTIAL || (a.splits == 1 && a.bias), VITSEG_EINVAL, "gemm_f32s: a direct epilogue takes one chunk and a bias");
+    VITSEG_CHECK_ARG(epi == SE_PARTIAL || (a.splits == 1 && (epi == SE_DGELU ? a.R != nullptr : a.bias != nullptr)), VITSEG_EINVAL,
+                     "gemm_f32s: a direct epilogue takes one chunk and its operand (bias / saved pre-activation)");
+    VITSEG_CHECK_ARG(amode != SA_PLAIN_WT || epi == SE_PARTIAL || epi == SE_DGELU, VITSEG_EINVAL, "gemm_f32s: the T-form serves the activation gradients");
     const int kc = amode == SA_CONV3 ? a.K : a.K / a.splits;
     VITSEG_CHECK_ARG(kc % 32 == 0 && (amode == SA_CONV3 || kc * a.splits == a.K), VITSEG_ESHAPE, "gemm_f32s: K chunk %d is not a multiple of 32", kc);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm_f32s: N / leading dimensions must be multiples of 4");
     VITSEG_CHECK_ARG(amode != SA_PATCH || ((a.P == 8 || a.P == 16 || a.P == 32) && a.S % 4 == 0), VITSEG_ESHAPE, "gemm_f32s: patch size %d", a.P);
-    VITSEG_CHECK_ARG((size_t)(a.M + 128) * a.lda * 4 < 0x7fffffffull && (size_t)a.N * a.ldw * 4 < 0x7fffffffull, VITSEG_ESHAPE,
+    VITSEG_CHECK_ARG((size_t)(a.M + 128) * a.lda * 4 < 0x7fffffffull && (size_t)(amode == SA_PLAIN_WT ? a.K : a.N) * a.ldw * 4 < 0x7fffffffull, VITSEG_ESHAPE,
                      "gemm_f32s: operand beyond one buffer descriptor");
     a.kh = epi == SE_PARTIAL ? 1 : small_pieces(a.K);
     const long env = opt(OPT_SMALL_VARIANT);   // 1..5: a tile variant of gemm_f32s_kernel; 6, 7: the one-image kernel (where it applies)
@@ -569,6 +596,7 @@ int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s) {
     a.tiles_n = (a.N + VARIANTS[a.variant].bn() - 1) / VARIANTS[a.variant].bn();
     if (amode == SA_CONV3) return launch_variant<SE_PARTIAL, SA_CONV3>(a, s);
     if (amode == SA_PATCH) return launch_variant<SE_PARTIAL, SA_PATCH>(a, s);
+    if (amode == SA_PLAIN_WT) return epi == SE_DGELU ? launch_variant<SE_DGELU, SA_PLAIN_WT>(a, s) : launch_variant<SE_PARTIAL, SA_PLAIN_WT>(a, s);
     switch (epi) {
         case SE_PARTIAL: return launch_variant<SE_PARTIAL, SA_PLAIN>(a, s);
         case SE_BIAS: return launch_variant<SE_BIAS, SA_PLAIN>(a, s);

@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void resln_kernel(const SRows p) {
     float* xr = p.X + (size_t)row * p.D;
     // every load of the row is issued up front (out-of-range lanes re-read the last vector and are masked out below)
     f32x4 res[NV], acc[NV];
-    const float* rsrc = p.embed ? (cls_row ? p.pos : p.pos + (size_t)(1 + row % p.Np) * p.D) : xr;
+    const float* rsrc = p.embed ? (cls_row ? p.pos : p.pos + (size_t)(1 + row % p.Np) * p.D)
+                                : (p.Xres ? p.Xres + (size_t)row * p.D : xr);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = min(lane + 64 * i, nv - 1);
@@ -59,6 +60,14 @@ __global__ __launch_bounds__(256) void resln_kernel(const SRows p) {
             const f32x4 b4 = ((const f32x4*)p.bias)[min(lane + 64 * i, nv - 1)];
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][e] += b4[e];
+        }
+        if (p.drop.thresh) {   // the branch is dropped, not the residual (the mask of gemm.hip's EPI_RESADD: same key, same bits)
+            const unsigned key = drop_key(p.drop.seed, p.drop.stream, (unsigned)row);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[i][e] = drop_keep(key, (unsigned)(4 * (lane + 64 * i) + e), p.drop.thresh) ? acc[i][e] * p.drop.scale : 0.f;
         }
     }
 #pragma unroll
@@ -96,6 +105,19 @@ __global__ __launch_bounds__(256) void resln_kernel(const SRows p) {
             for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * wv[i][e] + bv[i][e];
             ((f32x4*)hr)[lane + 64 * i] = o;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void slabsum_kernel(const float* __restrict__ partial, size_t stride, int splits,
+                                                      float* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = ((const f32x4*)partial)[i];
+        for (int s = 1; s < splits; ++s) {
+            const f32x4 t = ((const f32x4*)(partial + (size_t)s * stride))[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += t[e];
+        }
+        ((f32x4*)out)[i] = v;
     }
 }
 
@@ -143,6 +165,15 @@ int launch_resln(const SRows& a, hipStream_t s) {
     else if (nvl <= 4) hipLaunchKernelGGL(resln_kernel<4>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(resln_kernel<8>, grid, dim3(256), 0, s, a);
     VITSEG_LAUNCH_CHECK("resln");
+    return VITSEG_OK;
+}
+
+int launch_slabsum(const float* partial, size_t split_stride, int splits, float* out, size_t n, hipStream_t s) {
+    VITSEG_CHECK_ARG(partial && out && splits >= 1 && n % 4 == 0 && split_stride % 4 == 0, VITSEG_EINVAL, "slabsum: bad arguments");
+    const size_t n4 = n / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(slabsum_kernel, dim3(blocks), dim3(256), 0, s, partial, split_stride, splits, out, n4);
+    VITSEG_LAUNCH_CHECK("slabsum");
     return VITSEG_OK;
 }
 

@@ -22,12 +22,14 @@ constexpr int SMALL_MAX_ROWS = 16384;
 enum SmallEpi {
     SE_PARTIAL = 0,   // C[s] = chunk sum s (no bias): consumed by resln_kernel / headfin_kernel
     SE_BIAS = 1,      // C = acc + bias            (fused QKV projection; one chunk)
-    SE_GELU = 2       // C = gelu_erf(acc + bias)  (fc1; one chunk)
+    SE_GELU = 2,      // C = gelu_erf(acc + bias)  (fc1; one chunk); SGemm::aux (optional) receives acc + bias (saved for the backward)
+    SE_DGELU = 3      // C = acc * gelu'(R)        (backward through the MLP activation; one chunk, no bias)
 };
 enum SmallAMode {
     SA_PLAIN = 0,   // A[m * lda + k]
     SA_CONV3 = 1,   // chunk s = tap (ky, kx) of the 3x3 head conv: rows of the token-major map shifted by the tap, zero outside
-    SA_PATCH = 2    // im2col of the NCHW image: row (b, gy, gx), k = (c, py, px)
+    SA_PATCH = 2,   // im2col of the NCHW image: row (b, gy, gx), k = (c, py, px)
+    SA_PLAIN_WT = 3 // A plain, W in T-form: W[k * ldw + n] (the activation-gradient GEMMs read nn.Linear weights as they lie)
 };
 
 struct SGemm {
@@ -35,6 +37,8 @@ struct SGemm {
     const float* W;      // [N, ldw] row-major (nn.Linear layout); conv3: (out, ky, kx, in) = [256, 9 D]
     const float* bias;   // [N] (SE_BIAS / SE_GELU)
     float* C;            // [M, ldc], SE_PARTIAL: slab s at C + s * split_stride
+    float* aux;          // SE_GELU: optional [M, ldc] pre-activation output
+    const float* R;      // SE_DGELU: [M, ldc] saved pre-activation
     int M, N, K;         // K: the whole reduction (conv3: per tap = D)
     int lda, ldw, ldc;
     int splits;          // chunks of K / splits values each (conv3: 9 taps)
@@ -50,9 +54,13 @@ struct SGemm {
 
 // chunks of a reduction of length K feeding N outputs per row (shape-only rule, see above)
 inline int small_splits(int N, int K) {
-    if (N > K) return 1;                       // wide outputs (QKV, fc1): enough tiles without a split, and fc1 needs GELU in the epilogue
-    const int chunk = K <= 1024 ? 256 : 512;   // o_proj (K = D): D / 256 chunks; fc2 (K = 3072): 6 chunks
-    return K % chunk == 0 && K > chunk ? K / chunk : 1;
+    if (N > K || K % 32) return 1;             // wide outputs (QKV, fc1): enough tiles without a split, and fc1 needs GELU in the epilogue
+    // chunk = the largest whole number of 32-value K steps up to 256 values (K <= 1024) / 512 values that divides K:
+    // o_proj (K = 768) 3 chunks, fc2 (K = 3072) 6, the QKV activation gradient (K = 2304) 6 chunks of 384
+    const int steps = K / 32, cmax = K <= 1024 ? 8 : 16;
+    int c = cmax < steps ? cmax : steps;
+    while (steps % c) --c;
+    return steps / c;
 }
 // pieces of a direct-epilogue reduction (one chunk): out = ((h0 + h1) + h2) + h3 + bias, h_i = the fmaf chain over the i-th
 // quarter of K -- a shape-only rule like small_splits (the one-image kernel computes the quarters on four waves at once)
@@ -75,8 +83,12 @@ struct SRows {
     float* H;                 // [rows, D]
     int rows, Mp, Np, D, ln_rows, embed;
     float eps;
+    const float* Xres;        // residual source when it is not X itself (the training forward keeps every block input); null: X
+    DropArgs drop;            // training: x = residual + dropout(chunk sum + bias)  (hidden dropout, modeling_vit.py:276,283)
 };
 int launch_resln(const SRows& a, hipStream_t s);
+// out[i] = slab 0 [i] + slab 1 [i] + ... (chunk order): the activation gradients that a LayerNorm / attention backward reads
+int launch_slabsum(const float* partial, size_t split_stride, int splits, float* out, size_t n, hipStream_t s);
 
 // seg_head tail: F = relu(sum of the 9 tap slabs + b0) (256 mid channels), Z[b, c, y, x] = W2[c] . F + b2[c]
 int launch_headfin(const float* partial, size_t split_stride, const float* b0, const float* W2, const float* b2, float* Z,

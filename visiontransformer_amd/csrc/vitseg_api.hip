@@ -708,6 +708,25 @@ int vitseg_op_linear_resln_f32_small(const float* A, const float* Wt, const floa
     return launch_resln(r, (hipStream_t)stream);
 }
 
+int vitseg_op_dgrad_f32_small(const float* dY, const float* Wt, const float* R, float* dX, float* scratch, size_t scratch_floats,
+                              int M, int Nd, int Kd, int epilogue, void* stream) {
+    VITSEG_CHECK_ARG(dY && Wt && dX, VITSEG_EINVAL, "dgrad_f32_small: null pointer");
+    VITSEG_CHECK_ARG(epilogue == EPI_BIAS || (epilogue == EPI_DGELU && R), VITSEG_EINVAL, "dgrad_f32_small: epilogue %d", epilogue);
+    SGemm g{};
+    g.A = dY; g.W = Wt; g.M = M; g.N = Kd; g.K = Nd; g.lda = Nd; g.ldw = Kd; g.ldc = Kd;
+    if (epilogue == EPI_DGELU) {
+        VITSEG_CHECK_ARG(small_splits(Kd, Nd) == 1, VITSEG_ESHAPE, "dgrad_f32_small: the dGELU form is the wide one (Kd > Nd)");
+        g.C = dX; g.R = R; g.splits = 1;
+        return launch_gemm_f32s(g, SE_DGELU, SA_PLAIN_WT, (hipStream_t)stream);
+    }
+    g.splits = small_splits(Kd, Nd);
+    g.split_stride = (size_t)M * Kd;
+    VITSEG_CHECK_ARG(g.splits == 1 || (scratch && scratch_floats >= g.splits * g.split_stride), VITSEG_EWORKSPACE, "dgrad_f32_small: scratch");
+    g.C = g.splits > 1 ? scratch : dX;
+    if (int rc = launch_gemm_f32s(g, SE_PARTIAL, SA_PLAIN_WT, (hipStream_t)stream)) return rc;
+    return g.splits > 1 ? launch_slabsum(scratch, g.split_stride, g.splits, dX, (size_t)M * Kd, (hipStream_t)stream) : VITSEG_OK;
+}
+
 int vitseg_op_attention_f32_small(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
     return launch_attention_small(qkv, ctx, batch, num_patches, num_heads, (hipStream_t)stream);
 }
