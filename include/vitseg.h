@@ -178,6 +178,9 @@ int vitseg_op_linear_resln_f32_small(const float* A, const float* W, const float
  * floats, summed in chunk order); epilogue 5: dX *= gelu'(R) with R[M, Kd] the saved pre-activation (the wide form). */
 int vitseg_op_dgrad_f32_small(const float* dY, const float* W, const float* R, float* dX, float* scratch, size_t scratch_floats,
                               int M, int Nd, int Kd, int epilogue, void* stream);
+/* ... and its weight gradient  dW[Nd, Kd] = dY[M, Nd]^T . X[M, Kd]  (both operands token-major as they lie; the M token rows are
+ * the reduction, one fp32 fmaf chain in row order) */
+int vitseg_op_wgrad_f32_small(const float* dY, const float* X, float* dW, int M, int Nd, int Kd, void* stream);
 /* diagnostics: vitseg_op_linear_f32_small with per-block time stamps written by the kernel (8 words per block: s_memrealtime
  * at entry / exit, s_memtime at entry / after the prologue / after the K loop / at exit, HW_ID, XCC_ID; `stamps` must hold
  * 8 words per launched block) and `lds_pad` extra bytes of LDS per block (limits the blocks per CU).  tools/small_stamps.py. */

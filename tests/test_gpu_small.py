@@ -128,6 +128,22 @@ def test_dgrad_small_t_form(M, Nd, Kd, epi):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("M,Nd,Kd", [(788, 768, 3072), (788, 3072, 768), (392, 256, 6912), (784, 192, 768), (33, 64, 100), (197, 2304, 768)])
+def test_wgrad_small_both_operands_token_major(M, Nd, Kd):
+    """dW = dY^T X with the token rows as the reduction (a ragged last 32-row step) against fp64, every tile variant."""
+    dY, X = _rand(M, Nd, seed=3).to(DEV), _rand(M, Kd, seed=4).to(DEV)
+    ref = dY.double().T @ X.double()
+    outs = []
+    for v in range(0, NVARIANTS + 1):
+        dW = torch.full((Nd, Kd), float("nan"), device=DEV)
+        with _lib.option("small_variant", v):
+            _lib.check(_lib.lib().vitseg_op_wgrad_f32_small(dY.data_ptr(), X.data_ptr(), dW.data_ptr(), M, Nd, Kd, _stream()))
+        outs.append(dW)
+    assert (outs[0].double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def _attention_ref(qkv, B, Np, A):
     """fp64 softmax(q k^T / 8) v on the patches-first row layout (patch token t of image b in row b Np + t, CLS in row B Np + b)."""
     D = 64 * A

@@ -75,11 +75,14 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
         r[3] = 0x00020000;
         return r;
     };
-    const i32x4 ra = AMODE == SA_PLAIN || AMODE == SA_PLAIN_WT ? make_rsrc(p.A + (size_t)m0 * p.lda, (long long)(p.M - m0) * p.lda * 4)
+    constexpr bool WT = AMODE == SA_PLAIN_WT || AMODE == SA_TT;   // W[k][n] (n contiguous): the stage's W region is [32 k][BN n]
+    constexpr bool AT = AMODE == SA_TT;                           // A[k][m] likewise: [32 k][BM m]
+    const long long krows = AT && p.kvalid > 0 ? p.kvalid : p.K;  // rows of the T-form operands that exist (the rest reads as zeros)
+    const i32x4 ra = AMODE == SA_TT ? make_rsrc(p.A + m0, (krows * p.lda - m0) * 4)
+                     : AMODE == SA_PLAIN || AMODE == SA_PLAIN_WT ? make_rsrc(p.A + (size_t)m0 * p.lda, (long long)(p.M - m0) * p.lda * 4)
                      : AMODE == SA_CONV3 ? make_rsrc(p.A, (long long)p.M * p.lda * 4)
                                          : make_rsrc(p.A, (long long)(p.M / p.Np) * p.Cin * p.S * p.S * 4);
-    constexpr bool WT = AMODE == SA_PLAIN_WT;   // W[k][n] (n contiguous): the stage's W region is [32 k][BN n]
-    const i32x4 rw = WT ? make_rsrc(p.W + n0, ((long long)p.K * p.ldw - n0) * 4)
+    const i32x4 rw = WT ? make_rsrc(p.W + n0, (krows * p.ldw - n0) * 4)
                         : make_rsrc(p.W + (size_t)n0 * p.ldw, (long long)(p.N - n0) * p.ldw * 4);
 
     // Barrier protocol (all five waves): B0 = K step 0 has landed; B(kt + 1), kt = 0 .. KT - 2 = step kt + 1 has landed AND
@@ -102,7 +105,10 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
 #pragma unroll
         for (int q = 0; q < PIECES; ++q) {
             const int row = 8 * q + (lane >> 3), pos = lane & 7;
-            if (q < BM / 8) {
+            if (q < BM / 8 && AT) {
+                const unsigned off = (unsigned)(q * 1024 + 16 * lane);   // the [32 k][BM m] region in order, as the T-form W below
+                voff[q] = (off / (BM * 4)) * (unsigned)p.lda * 4u + off % (BM * 4);
+            } else if (q < BM / 8) {
                 const int chunk = pos ^ ((row >> 1) & 7);
                 if (AMODE == SA_PLAIN || AMODE == SA_PLAIN_WT) {
                     voff[q] = (unsigned)row * (unsigned)p.lda * 4u + (unsigned)(chunk * 16);
@@ -130,6 +136,7 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
         const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
         // scalar byte offsets of K step kt: W columns k0w + 32 kt; A by mode
         auto soff_a = [&](int kt) -> unsigned {
+            if (AT) return (unsigned)(k0w + 32 * kt) * (unsigned)p.lda * 4u;
             if (AMODE == SA_PLAIN || AMODE == SA_PLAIN_WT) return (unsigned)(k0w + 32 * kt) * 4u;
             if (AMODE == SA_CONV3) return (unsigned)(32 * kt) * 4u;
             const int k = k0w + 32 * kt, pp = p.P * p.P;      // patch: k = (c, py, px); 32 | P^2 and P | 32 kt (P = 8, 16, 32)
@@ -179,8 +186,15 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
     auto read_frags = [&](int stage, int j, int slot) {
         const int ab = stage * STAGE + wr * MT * 4096 + offj[j];
         const int wb = stage * STAGE + BM * 128 + wc * NT * 4096 + offj[j];
+        if (AT) {
+            const float* ar_ = (const float*)(lds + stage * STAGE) + (8 * j + 4 * lh) * BM + wr * MT * 32 + li;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) fa[slot][mt] = *(const f32x4*)(lds + ab + mt * 4096);
+            for (int mt = 0; mt < MT; ++mt)
+                fa[slot][mt] = f32x4{ar_[mt * 32], ar_[BM + mt * 32], ar_[2 * BM + mt * 32], ar_[3 * BM + mt * 32]};
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[slot][mt] = *(const f32x4*)(lds + ab + mt * 4096);
+        }
         if (WT) {   // [k][n] region: lane (li, lh) gathers k = 8 j + 4 lh + e, n = its column -- four conflict-free 4-byte reads
             const float* wr_ = (const float*)(lds + stage * STAGE + BM * 128) + (8 * j + 4 * lh) * BN + wc * NT * 32 + li;
 #pragma unroll
@@ -575,11 +589,12 @@ int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s) {
     VITSEG_CHECK_ARG(epi == SE_PARTIAL || (a.splits == 1 && (epi == SE_DGELU ? a.R != nullptr : a.bias != nullptr)), VITSEG_EINVAL,
                      "gemm_f32s: a direct epilogue takes one chunk and its operand (bias / saved pre-activation)");
     VITSEG_CHECK_ARG(amode != SA_PLAIN_WT || epi == SE_PARTIAL || epi == SE_DGELU, VITSEG_EINVAL, "gemm_f32s: the T-form serves the activation gradients");
+    VITSEG_CHECK_ARG(amode != SA_TT || (epi == SE_PARTIAL && a.splits == 1), VITSEG_EINVAL, "gemm_f32s: the TT form writes one plain chunk");
     const int kc = amode == SA_CONV3 ? a.K : a.K / a.splits;
     VITSEG_CHECK_ARG(kc % 32 == 0 && (amode == SA_CONV3 || kc * a.splits == a.K), VITSEG_ESHAPE, "gemm_f32s: K chunk %d is not a multiple of 32", kc);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm_f32s: N / leading dimensions must be multiples of 4");
     VITSEG_CHECK_ARG(amode != SA_PATCH || ((a.P == 8 || a.P == 16 || a.P == 32) && a.S % 4 == 0), VITSEG_ESHAPE, "gemm_f32s: patch size %d", a.P);
-    VITSEG_CHECK_ARG((size_t)(a.M + 128) * a.lda * 4 < 0x7fffffffull && (size_t)(amode == SA_PLAIN_WT ? a.K : a.N) * a.ldw * 4 < 0x7fffffffull, VITSEG_ESHAPE,
+    VITSEG_CHECK_ARG((size_t)(amode == SA_TT ? a.K : a.M + 128) * a.lda * 4 < 0x7fffffffull && (size_t)(amode == SA_PLAIN_WT || amode == SA_TT ? a.K : a.N) * a.ldw * 4 < 0x7fffffffull, VITSEG_ESHAPE,
                      "gemm_f32s: operand beyond one buffer descriptor");
     a.kh = epi == SE_PARTIAL ? 1 : small_pieces(a.K);
     const long env = opt(OPT_SMALL_VARIANT);   // 1..5: a tile variant of gemm_f32s_kernel; 6, 7: the one-image kernel (where it applies)
@@ -596,6 +611,7 @@ int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s) {
     a.tiles_n = (a.N + VARIANTS[a.variant].bn() - 1) / VARIANTS[a.variant].bn();
     if (amode == SA_CONV3) return launch_variant<SE_PARTIAL, SA_CONV3>(a, s);
     if (amode == SA_PATCH) return launch_variant<SE_PARTIAL, SA_PATCH>(a, s);
+    if (amode == SA_TT) return launch_variant<SE_PARTIAL, SA_TT>(a, s);
     if (amode == SA_PLAIN_WT) return epi == SE_DGELU ? launch_variant<SE_DGELU, SA_PLAIN_WT>(a, s) : launch_variant<SE_PARTIAL, SA_PLAIN_WT>(a, s);
     switch (epi) {
         case SE_PARTIAL: return launch_variant<SE_PARTIAL, SA_PLAIN>(a, s);

@@ -127,7 +127,8 @@ constexpr int MID = 256;   // seg_head.0 output channels (model/CE/classes.py:24
 // seg_head.2 against it (wave reductions), Z[b, c, y, x] NCHW as head1x1_kernel writes it.
 __global__ __launch_bounds__(256) void headfin_kernel(const float* __restrict__ partial, size_t split_stride,
                                                       const float* __restrict__ b0, const float* __restrict__ W2,
-                                                      const float* __restrict__ b2, float* __restrict__ Z, int B, int Np, int C) {
+                                                      const float* __restrict__ b2, float* __restrict__ Z, int B, int Np, int C,
+                                                      float* __restrict__ F_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * Np) return;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void headfin_kernel(const float* __restrict__ 
     const f32x4 bb = ((const f32x4*)b0)[lane];
 #pragma unroll
     for (int e = 0; e < 4; ++e) f[e] = fmaxf(f[e] + bb[e], 0.f);
+    if (F_out) ((f32x4*)(F_out + (size_t)row * MID))[lane] = f;
     const int b = row / Np, tok = row - b * Np;
     for (int c = 0; c < C; ++c) {
         const f32x4 w = ((const f32x4*)(W2 + (size_t)c * MID))[lane];
@@ -178,9 +180,9 @@ int launch_slabsum(const float* partial, size_t split_stride, int splits, float*
 }
 
 int launch_headfin(const float* partial, size_t split_stride, const float* b0, const float* W2, const float* b2, float* Z,
-                   int B, int Np, int C, hipStream_t s) {
+                   int B, int Np, int C, hipStream_t s, float* F_out) {
     VITSEG_CHECK_ARG(partial && b0 && W2 && b2 && Z && B > 0 && Np > 0 && C > 0, VITSEG_EINVAL, "headfin: bad arguments");
-    hipLaunchKernelGGL(headfin_kernel, dim3((B * Np + 3) / 4), dim3(256), 0, s, partial, split_stride, b0, W2, b2, Z, B, Np, C);
+    hipLaunchKernelGGL(headfin_kernel, dim3((B * Np + 3) / 4), dim3(256), 0, s, partial, split_stride, b0, W2, b2, Z, B, Np, C, F_out);
     VITSEG_LAUNCH_CHECK("headfin");
     return VITSEG_OK;
 }

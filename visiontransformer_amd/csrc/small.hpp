@@ -29,7 +29,9 @@ enum SmallAMode {
     SA_PLAIN = 0,   // A[m * lda + k]
     SA_CONV3 = 1,   // chunk s = tap (ky, kx) of the 3x3 head conv: rows of the token-major map shifted by the tap, zero outside
     SA_PATCH = 2,   // im2col of the NCHW image: row (b, gy, gx), k = (c, py, px)
-    SA_PLAIN_WT = 3 // A plain, W in T-form: W[k * ldw + n] (the activation-gradient GEMMs read nn.Linear weights as they lie)
+    SA_PLAIN_WT = 3,// A plain, W in T-form: W[k * ldw + n] (the activation-gradient GEMMs read nn.Linear weights as they lie)
+    SA_TT = 4       // both in T-form: C[i][j] = sum_r A[r * lda + i] W[r * ldw + j], r < kvalid (weight gradients dW = dY^T X: the
+                    // reduction runs over the token rows of both operands; K = kvalid rounded up to 32, the tail reads as zeros)
 };
 
 struct SGemm {
@@ -44,6 +46,7 @@ struct SGemm {
     int splits;          // chunks of K / splits values each (conv3: 9 taps)
     size_t split_stride; // floats
     int tiles_m, tiles_n, variant;   // filled by the launcher (small_plan)
+    int kvalid;                      // SA_TT: token rows present (0: K)
     int kh;                          // direct epilogues: equal pieces the reduction is summed in (small_pieces(K)); filled by the launcher
     int g, Np, S, P, Cin;            // geometry of SA_CONV3 / SA_PATCH
     // diagnostics (tools/small_stamps.py; null in the product path): 8 words per block -- s_memrealtime at entry and exit,
@@ -91,8 +94,9 @@ int launch_resln(const SRows& a, hipStream_t s);
 int launch_slabsum(const float* partial, size_t split_stride, int splits, float* out, size_t n, hipStream_t s);
 
 // seg_head tail: F = relu(sum of the 9 tap slabs + b0) (256 mid channels), Z[b, c, y, x] = W2[c] . F + b2[c]
+// F_out (optional): the 256 ReLU'd mid features per pixel, kept for the backward
 int launch_headfin(const float* partial, size_t split_stride, const float* b0, const float* W2, const float* b2, float* Z,
-                   int B, int Np, int C, hipStream_t s);
+                   int B, int Np, int C, hipStream_t s, float* F_out = nullptr);
 
 // softmax(q k^T / 8) v for short sequences: one block per 32 queries of one (image, head), the four waves split the keys
 int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s);

@@ -727,6 +727,14 @@ int vitseg_op_dgrad_f32_small(const float* dY, const float* Wt, const float* R, 
     return g.splits > 1 ? launch_slabsum(scratch, g.split_stride, g.splits, dX, (size_t)M * Kd, (hipStream_t)stream) : VITSEG_OK;
 }
 
+int vitseg_op_wgrad_f32_small(const float* dY, const float* X, float* dW, int M, int Nd, int Kd, void* stream) {
+    VITSEG_CHECK_ARG(dY && X && dW && M > 0, VITSEG_EINVAL, "wgrad_f32_small: null pointer");
+    SGemm g{};
+    g.A = dY; g.W = X; g.C = dW; g.M = Nd; g.N = Kd; g.K = (M + 31) / 32 * 32; g.kvalid = M;
+    g.lda = Nd; g.ldw = Kd; g.ldc = Kd; g.splits = 1;
+    return launch_gemm_f32s(g, SE_PARTIAL, SA_TT, (hipStream_t)stream);
+}
+
 int vitseg_op_attention_f32_small(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
     return launch_attention_small(qkv, ctx, batch, num_patches, num_heads, (hipStream_t)stream);
 }
