@@ -355,6 +355,8 @@ int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_ou
                                  void* dqkv, int batch, int num_patches, int num_heads, float dropout_p,
                                  uint32_t dropout_seed, uint32_t dropout_stream, void* dropmask_words, float* dbias_qkv,
                                  void* stream);
+/* scratch of vitseg_op_layernorm_bwd_f32: per-block partial sums of dw / db (the block count depends on rows and on the device) */
+size_t vitseg_op_layernorm_bwd_scratch_floats(int rows, int D);
 int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out,
                                 float* dw, float* db, float* scratch, int rows, int D, float eps, void* stream);
 

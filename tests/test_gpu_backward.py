@@ -54,7 +54,7 @@ def test_gemm_operand_forms(M, N, K, ta, tb, epi):
     assert (C.cpu().double() - ref).abs().max().item() < bound
 
 
-@pytest.mark.parametrize("rows,D", [(7, 192), (1025, 768), (130, 1024), (64, 512)])
+@pytest.mark.parametrize("rows,D", [(7, 192), (1025, 768), (130, 1024), (64, 512), (788, 768), (20000, 192)])
 def test_layernorm_backward(rows, D):
     x = (_rand(rows, D, seed=1, scale=2.0) + 0.3).double().requires_grad_(True)
     w = (_rand(D, seed=2) + 1.0).double().requires_grad_(True)
@@ -64,7 +64,7 @@ def test_layernorm_backward(rows, D):
     y.backward(g.double())
     xd, wd, gd, rd = x.detach().float().to(DEV), w.detach().float().to(DEV), g.to(DEV), dres.to(DEV)
     out, dw, db = torch.empty(rows, D, device=DEV), torch.empty(D, device=DEV), torch.empty(D, device=DEV)
-    scratch = torch.empty(((rows + 63) // 64) * 2 * D, device=DEV)
+    scratch = torch.empty(_lib.lib().vitseg_op_layernorm_bwd_scratch_floats(rows, D), device=DEV)
     _lib.check(_lib.lib().vitseg_op_layernorm_bwd_f32(xd.data_ptr(), wd.data_ptr(), gd.data_ptr(), rd.data_ptr(),
                                                       out.data_ptr(), dw.data_ptr(), db.data_ptr(), scratch.data_ptr(),
                                                       rows, D, 1e-12, _stream()))

@@ -618,17 +618,27 @@ int launch_transpose_bf16(const void* in, void* out, int R, int C, int ldin, int
     return VITSEG_OK;
 }
 
-size_t layernorm_bwd_scratch_floats(int rows, int D) { return (size_t)((rows + 63) / 64) * 3 * D; }
+// grid of the LayerNorm backward: 64-row blocks, capped at what is resident at once (3 blocks of 4 waves per CU up to D = 768:
+// <= 168 VGPRs by __launch_bounds__, 36 KiB of LDS each; 2 beyond); few rows (the reference's batch 4 x 224x224: 788) are cut
+// finer, 8 rows per block, instead of 13 blocks on 256 CUs (22 -> 8 us per launch)
+static int lnb_blocks(int rows, int D) {
+    const int nvl = (D / 4 + 63) / 64;
+    const int cap = (nvl <= 3 ? 3 : 2) * device_num_cus();
+    const int per = rows < 64 * device_num_cus() ? 8 : 64;
+    const int b = (rows + per - 1) / per;
+    return b < cap ? b : cap;
+}
+size_t layernorm_bwd_scratch_floats(int rows, int D) {
+    const size_t fine = (size_t)(rows + 7) / 8, coarse = (size_t)(rows + 63) / 64;   // (an upper bound of lnb_blocks for any CU count)
+    return (fine < 4096 ? (fine > coarse ? fine : coarse) : coarse) * 3 * D;
+}
 int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is_bf16, const float* dres_in,
                          float* dres_out, float* dw, float* db, float* scratch, int rows, int D, float eps,
                          hipStream_t s, void* br_out, DropArgs br_drop, float* br_dbias) {
     VITSEG_CHECK_ARG(D % 4 == 0 && D <= 1024, VITSEG_ESHAPE, "layernorm_bwd: D=%d must be a multiple of 4, <= 1024", D);
     VITSEG_CHECK_ARG(!br_out || (g_is_bf16 && br_dbias), VITSEG_EINVAL, "layernorm_bwd: branch output needs bf16 g + dbias");
-    // grid: 64-row blocks, capped at what is resident at once (3 blocks of 4 waves per CU up to D = 768: <= 168 VGPRs
-    // by __launch_bounds__, 36 KiB of LDS each; 2 beyond)
     const int nvl = (D / 4 + 63) / 64;
-    const int cap = (nvl <= 3 ? 3 : 2) * device_num_cus();
-    const int blocks = (rows + 63) / 64 < cap ? (rows + 63) / 64 : cap;
+    const int blocks = lnb_blocks(rows, D);
 #define VITSEG_LNB(NV)                                                                                            \
     do {                                                                                                          \
         if (br_out)                                                                                               \

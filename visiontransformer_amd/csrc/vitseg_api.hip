@@ -647,6 +647,8 @@ int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_ou
                                      (hipStream_t)stream, mw, dbias_qkv);
 }
 
+size_t vitseg_op_layernorm_bwd_scratch_floats(int rows, int D) { return rows > 0 && D > 0 ? layernorm_bwd_scratch_floats(rows, D) : 0; }
+
 int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out,
                                 float* dw, float* db, float* scratch, int rows, int D, float eps, void* stream) {
     return launch_layernorm_bwd(x, w, g, 0, dres_in, dres_out, dw, db, scratch, rows, D, eps, (hipStream_t)stream);
