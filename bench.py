@@ -616,6 +616,44 @@ def side_train_dist(cfg, sd_np, rank, world, dev, barrier, batch=64, steps=4):
     return out
 
 
+def side_ref_grid(dev, reps=10):
+    """The reference's own published regime inside the default line (rank 0, N = 1, outside the timed region; the full table with
+    the hipGraph column, the oracle check and the CPU baseline per configuration is `--workload ref_grid`): every configuration of
+    predict.CONFIGURATIONS at batch 4 x 224x224, 17 classes, fp32 forward -> logits + mask; ViT-B/16 also at batch 1 (the worker's
+    call) and its training step at the reference's batch (model/CE/trainCurrentViTmodel.py:57)."""
+    from visiontransformer_amd.config import ViTSegConfig
+    from visiontransformer_amd.predict import CONFIGURATIONS
+    out = {"workload": "fp32 forward (logits + mask) of the nine published configurations, batch 4 x 224x224, 17 classes; "
+                       "published = mean Inference_Time per image of model/CE/test/*/*_metrics.csv (hardware unstated)", "configs": {}}
+    for cid in sorted(CONFIGURATIONS):
+        P, D, L, A = CONFIGURATIONS[cid]
+        cfg = ViTSegConfig(17, P, D, L, A, image_size=224)
+        model = ViTSegmentationModel(17, P, D, L, A, image_size=224, device=dev).eval()   # random init: a throughput figure
+        x = torch.from_numpy(synth.make_images(cfg, 4, seed=0)).to(dev)
+        with torch.no_grad():
+            for _ in range(3):
+                model.predict_mask(x, return_logits=True)
+            t4 = time_calls(lambda: model.predict_mask(x, return_logits=True), reps, rounds=3)
+            e = {"ms_batch4": round(t4 * 1e3, 3), "frac_of_fp32_peak": round(4 * cfg.forward_flops_per_image() / t4 / 1e12 / PEAK_TFLOPS["f32"], 4),
+                 "x_published": round(REF_PUBLISHED_S_PER_IMAGE[cid] / (t4 / 4), 1)}
+            if cid == 0:
+                for _ in range(3):
+                    model.predict_mask(x[:1], return_logits=True)
+                e["ms_batch1"] = round(time_calls(lambda: model.predict_mask(x[:1], return_logits=True), reps, rounds=3) * 1e3, 3)
+        if cid == 0:
+            del model
+            y4 = torch.from_numpy(synth.make_targets(cfg, 4, seed=0, size=224)).to(dev)
+            mt = ViTSegmentationModel(17, P, D, L, A, image_size=224, device=dev, dropout=0.1)
+            el, _, _ = run_train_steps(mt, x, y4, 1, 10, 3, 0, lambda: None)
+            e["train_step_ms_batch4_fp32"] = round(el / 10 * 1e3, 3)
+            del mt
+            model = None
+        out["configs"][f"P{P}H{D}A{A}"] = e
+        del model, x
+        torch.cuda.empty_cache()
+    return out
+
+
 def side_serve(dev, seconds=6.0):
     """The worker's request path end to end on the device (rows f3 + path + f4 of SURVEY.md section 8 chained; contract:
     /root/reference/backend/core/views.py:97-149, body modelled on model/CE/testViTModel.py:92-126): decoded uint8 photos
@@ -933,6 +971,7 @@ def main():
             x = None
             out["l16_1024_tiled_f16_path"] = side_l16_tiled_f16(dev)
             out["serve_path"] = side_serve(dev)
+            out["ref_grid_path"] = side_ref_grid(dev)
         print(json.dumps(out), flush=True)
     barrier()
     if world > 1:
