@@ -154,3 +154,19 @@ def test_dispatcher_options_table():
     env = dict(os.environ, VITSEG_NO_H16P="1", VITSEG_BF16_TILES="large", VITSEG_DROPW_LIMIT_MB="64")
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, check=True).stdout.split()
     assert out == ["1", "2", "64"], out
+    # a numeric value is taken as is (=0 leaves a switch OFF, as vitseg_set_option(name, 0) does); empty / non-numeric = 1
+    code = ("from visiontransformer_amd import _lib; "
+            "print(*[_lib.get_option(n) for n in ('no_p8', 'no_mask2', 'no_small', 'no_f32p', 'small_max_rows', 'small_variant')])")
+    env = dict(os.environ, VITSEG_NO_P8="0", VITSEG_NO_MASK2="", VITSEG_NO_SMALL="yes", VITSEG_NO_F32P="1", VITSEG_SMALL_MAX_ROWS="4096")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["0", "1", "1", "1", "4096", "0"], out
+
+
+def test_small_route_summation_rules_are_functions_of_the_shape():
+    """csrc/small.hpp: the chunk count of a reduction (vitseg_small_splits) -- host arithmetic, no GPU needed: wide outputs are one
+    chunk; o_proj / fc2 / the patch embedding / the activation gradients of the reference's three widths get the documented counts."""
+    f = _lib.lib().vitseg_small_splits
+    assert [f(2304, 768), f(3072, 768), f(1536, 512), f(3072, 1024)] == [1, 1, 1, 1]           # QKV, fc1: N > K
+    assert [f(768, 768), f(768, 3072), f(512, 512), f(512, 3072), f(1024, 1024), f(1024, 3072)] == [3, 6, 2, 6, 4, 6]
+    assert [f(768, 2304), f(512, 1536), f(1024, 3072)] == [6, 3, 6]                               # dH1 = dQKV . Wqkv
+    assert [f(192, 192), f(192, 3072), f(192, 576), f(768, 100)] == [1, 6, 3, 1]                   # Tiny/16; K % 32 != 0: one chunk
