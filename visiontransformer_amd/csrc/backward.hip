@@ -575,7 +575,38 @@ int launch_colsum_finish_fused(const void* tail_rows, int tail, int chunk0, floa
     VITSEG_LAUNCH_CHECK("colsum_finish");
     return VITSEG_OK;
 }
+// Few rows (the reference's batch 4 x 224x224: 788): one launch -- a block owns 16 columns, its 16 row groups walk the rows
+// 16 apart (64-byte pieces of a row per group), LDS combines the groups in group order -- instead of the partial + finish pair
+// (7 + 5 us, fifty times per training step).
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ X, float* __restrict__ out, int M, int N, int ld) {
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < N) {
+        int r = rg;
+        for (; r + 16 < M; r += 32) {
+            s0 += X[(size_t)r * ld + col];
+            s1 += X[(size_t)(r + 16) * ld + col];
+        }
+        if (r < M) s0 += X[(size_t)r * ld + col];
+    }
+    red[rg][c] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && col < N) {
+        float t = red[0][c];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += red[g][c];
+        out[col] = t;
+    }
+}
+
 int launch_colsum(const void* X, int x_is_bf16, float* out, float* scratch, int M, int N, int ld, hipStream_t s) {
+    if (!x_is_bf16 && M <= 4096) {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((N + 15) / 16), dim3(256), 0, s, (const float*)X, out, M, N, ld);
+        VITSEG_LAUNCH_CHECK("colsum_small");
+        return VITSEG_OK;
+    }
     const int chunks = (M + 255) / 256;
     if (x_is_bf16)
         hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3((N + 255) / 256, chunks), dim3(256), 0, s,

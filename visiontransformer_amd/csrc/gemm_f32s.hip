@@ -62,7 +62,7 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
     const int tm = t % p.tiles_m, t1 = t / p.tiles_m;
     const int tn = t1 % p.tiles_n, sp = t1 / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kc = AMODE == SA_CONV3 ? p.K : p.K / p.splits;   // conv3: one tap (K = D values) per chunk
+    const int kc = AMODE == SA_CONV3 ? p.K : AMODE == SA_CONV3_ALL ? 9 * p.K : p.K / p.splits;   // conv3: one tap (K = D values) per chunk
     const int KT = kc / 32;
     const int k0w = sp * kc;                                    // first W column of this chunk
 
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
     const long long krows = AT && p.kvalid > 0 ? p.kvalid : p.K;  // rows of the T-form operands that exist (the rest reads as zeros)
     const i32x4 ra = AMODE == SA_TT ? make_rsrc(p.A + m0, (krows * p.lda - m0) * 4)
                      : AMODE == SA_PLAIN || AMODE == SA_PLAIN_WT ? make_rsrc(p.A + (size_t)m0 * p.lda, (long long)(p.M - m0) * p.lda * 4)
-                     : AMODE == SA_CONV3 ? make_rsrc(p.A, (long long)p.M * p.lda * 4)
+                     : AMODE == SA_CONV3 || AMODE == SA_CONV3_ALL ? make_rsrc(p.A, (long long)p.M * p.lda * 4)
                                          : make_rsrc(p.A, (long long)(p.M / p.Np) * p.Cin * p.S * p.S * 4);
     const i32x4 rw = WT ? make_rsrc(p.W + n0, (krows * p.ldw - n0) * 4)
                         : make_rsrc(p.W + (size_t)n0 * p.ldw, (long long)(p.N - n0) * p.ldw * 4);
@@ -102,10 +102,23 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
             dx = sp % 3 - 1;
         }
         unsigned voff[PIECES];
+        auto set_tap = [&](int tap) {   // SA_CONV3_ALL: the A rows of tap (ky, kx) = the map shifted by the tap, zero outside the image
+            const int ty = tap / 3 - 1, tx = tap % 3 - 1;
+#pragma unroll
+            for (int q = 0; q < BM / 8; ++q) {
+                const int row = 8 * q + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+                const int r = m0 + row;
+                const int rem = r % p.Np, y = rem / p.g + ty, x = rem % p.g + tx;
+                const bool ok = r < p.M && y >= 0 && y < p.g && x >= 0 && x < p.g;
+                voff[q] = ok ? (unsigned)(r + ty * p.g + tx) * (unsigned)p.lda * 4u + (unsigned)(chunk * 16) : OOB;
+            }
+        };
 #pragma unroll
         for (int q = 0; q < PIECES; ++q) {
             const int row = 8 * q + (lane >> 3), pos = lane & 7;
-            if (q < BM / 8 && AT) {
+            if (q < BM / 8 && AMODE == SA_CONV3_ALL) {
+                voff[q] = OOB;   // (set_tap fills these per tap)
+            } else if (q < BM / 8 && AT) {
                 const unsigned off = (unsigned)(q * 1024 + 16 * lane);   // the [32 k][BM m] region in order, as the T-form W below
                 voff[q] = (off / (BM * 4)) * (unsigned)p.lda * 4u + off % (BM * 4);
             } else if (q < BM / 8) {
@@ -139,10 +152,12 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
             if (AT) return (unsigned)(k0w + 32 * kt) * (unsigned)p.lda * 4u;
             if (AMODE == SA_PLAIN || AMODE == SA_PLAIN_WT) return (unsigned)(k0w + 32 * kt) * 4u;
             if (AMODE == SA_CONV3) return (unsigned)(32 * kt) * 4u;
+            if (AMODE == SA_CONV3_ALL) return (unsigned)(32 * (kt % (p.K / 32))) * 4u;
             const int k = k0w + 32 * kt, pp = p.P * p.P;      // patch: k = (c, py, px); 32 | P^2 and P | 32 kt (P = 8, 16, 32)
             return (unsigned)((k / pp) * p.S * p.S + ((k % pp) / p.P) * p.S) * 4u;
         };
         auto dma_step = [&](int kt) {   // K step kt into ring stage kt % NSTAGE
+            if (AMODE == SA_CONV3_ALL && kt % (p.K / 32) == 0) set_tap(kt / (p.K / 32));
             const unsigned sb = lds_base + (unsigned)((kt % NSTAGE) * STAGE);
             const unsigned sa = soff_a(kt), sw_ = WT ? (unsigned)(k0w + 32 * kt) * (unsigned)p.ldw * 4u : (unsigned)(k0w + 32 * kt) * 4u;
 #pragma unroll
@@ -298,7 +313,7 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
                 *(f32x4*)(slab + li * 32 + (((2 * q + lh) ^ (li & 7)) << 2)) = f32x4{tl[4 * q], tl[4 * q + 1], tl[4 * q + 2], tl[4 * q + 3]};
             const int gcol = n0 + (wc * NT + nt) * 32 + c8 * 4;
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-            if ((EPI == SE_BIAS || EPI == SE_GELU) && gcol < p.N) bias4 = *(const f32x4*)(p.bias + gcol);
+            if ((EPI == SE_BIAS || EPI == SE_GELU || EPI == SE_RELU) && gcol < p.N) bias4 = *(const f32x4*)(p.bias + gcol);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int row = 8 * ps + rrow;
@@ -314,6 +329,10 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                     }
+                }
+                if (EPI == SE_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
                 }
                 if (EPI == SE_DGELU) {
                     f32x4 u = {0.f, 0.f, 0.f, 0.f};
@@ -590,13 +609,14 @@ int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s) {
                      "gemm_f32s: a direct epilogue takes one chunk and its operand (bias / saved pre-activation)");
     VITSEG_CHECK_ARG(amode != SA_PLAIN_WT || epi == SE_PARTIAL || epi == SE_DGELU, VITSEG_EINVAL, "gemm_f32s: the T-form serves the activation gradients");
     VITSEG_CHECK_ARG(amode != SA_TT || (epi == SE_PARTIAL && a.splits == 1), VITSEG_EINVAL, "gemm_f32s: the TT form writes one plain chunk");
-    const int kc = amode == SA_CONV3 ? a.K : a.K / a.splits;
-    VITSEG_CHECK_ARG(kc % 32 == 0 && (amode == SA_CONV3 || kc * a.splits == a.K), VITSEG_ESHAPE, "gemm_f32s: K chunk %d is not a multiple of 32", kc);
+    const int kc = amode == SA_CONV3 ? a.K : amode == SA_CONV3_ALL ? 9 * a.K : a.K / a.splits;
+    VITSEG_CHECK_ARG(kc % 32 == 0 && a.K % 32 == 0 && (amode == SA_CONV3 || amode == SA_CONV3_ALL || kc * a.splits == a.K), VITSEG_ESHAPE, "gemm_f32s: K chunk %d is not a multiple of 32", kc);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm_f32s: N / leading dimensions must be multiples of 4");
     VITSEG_CHECK_ARG(amode != SA_PATCH || ((a.P == 8 || a.P == 16 || a.P == 32) && a.S % 4 == 0), VITSEG_ESHAPE, "gemm_f32s: patch size %d", a.P);
     VITSEG_CHECK_ARG((size_t)(amode == SA_TT ? a.K : a.M + 128) * a.lda * 4 < 0x7fffffffull && (size_t)(amode == SA_PLAIN_WT || amode == SA_TT ? a.K : a.N) * a.ldw * 4 < 0x7fffffffull, VITSEG_ESHAPE,
                      "gemm_f32s: operand beyond one buffer descriptor");
-    a.kh = epi == SE_PARTIAL ? 1 : small_pieces(a.K);
+    a.kh = epi == SE_PARTIAL || amode == SA_CONV3_ALL ? 1 : small_pieces(a.K);   // (the whole conv is ONE chain, as gemm.hip computes it)
+    VITSEG_CHECK_ARG((amode == SA_CONV3_ALL) == (epi == SE_RELU), VITSEG_EINVAL, "gemm_f32s: SE_RELU is the whole-conv epilogue");
     const long env = opt(OPT_SMALL_VARIANT);   // 1..5: a tile variant of gemm_f32s_kernel; 6, 7: the one-image kernel (where it applies)
     a.variant = env > 0 && env <= NVARIANTS + 2 ? (int)env - 1 : small_plan(a, kc, epi, amode);
     if (a.variant >= KW_FIRST && !kw_applies(a, epi, amode, a.variant - KW_FIRST + 2)) a.variant = small_plan(a, kc, epi, amode);
@@ -611,6 +631,7 @@ int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s) {
     a.tiles_n = (a.N + VARIANTS[a.variant].bn() - 1) / VARIANTS[a.variant].bn();
     if (amode == SA_CONV3) return launch_variant<SE_PARTIAL, SA_CONV3>(a, s);
     if (amode == SA_PATCH) return launch_variant<SE_PARTIAL, SA_PATCH>(a, s);
+    if (amode == SA_CONV3_ALL) return launch_variant<SE_RELU, SA_CONV3_ALL>(a, s);
     if (amode == SA_TT) return launch_variant<SE_PARTIAL, SA_TT>(a, s);
     if (amode == SA_PLAIN_WT) return epi == SE_DGELU ? launch_variant<SE_DGELU, SA_PLAIN_WT>(a, s) : launch_variant<SE_PARTIAL, SA_PLAIN_WT>(a, s);
     switch (epi) {

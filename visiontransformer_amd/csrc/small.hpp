@@ -23,13 +23,17 @@ enum SmallEpi {
     SE_PARTIAL = 0,   // C[s] = chunk sum s (no bias): consumed by resln_kernel / headfin_kernel
     SE_BIAS = 1,      // C = acc + bias            (fused QKV projection; one chunk)
     SE_GELU = 2,      // C = gelu_erf(acc + bias)  (fc1; one chunk); SGemm::aux (optional) receives acc + bias (saved for the backward)
-    SE_DGELU = 3      // C = acc * gelu'(R)        (backward through the MLP activation; one chunk, no bias)
+    SE_DGELU = 3,     // C = acc * gelu'(R)        (backward through the MLP activation; one chunk, no bias)
+    SE_RELU = 4       // C = max(acc + bias, 0)    (the 3x3 head conv as ONE chain over its nine taps, SA_CONV3_ALL)
 };
 enum SmallAMode {
     SA_PLAIN = 0,   // A[m * lda + k]
     SA_CONV3 = 1,   // chunk s = tap (ky, kx) of the 3x3 head conv: rows of the token-major map shifted by the tap, zero outside
     SA_PATCH = 2,   // im2col of the NCHW image: row (b, gy, gx), k = (c, py, px)
     SA_PLAIN_WT = 3,// A plain, W in T-form: W[k * ldw + n] (the activation-gradient GEMMs read nn.Linear weights as they lie)
+    SA_CONV3_ALL = 5,// the whole 3x3 conv in one launch and ONE fmaf chain per output, k = (ky, kx, d) as gemm.hip's implicit GEMM
+                    // walks it (bit-identical to that kernel; K = D per tap, 9 D in all): the training forward's head conv, whose
+                    // ReLU mask must not depend on a summation order (profiles/r05_notes.md)
     SA_TT = 4       // both in T-form: C[i][j] = sum_r A[r * lda + i] W[r * ldw + j], r < kvalid (weight gradients dW = dY^T X: the
                     // reduction runs over the token rows of both operands; K = kvalid rounded up to 32, the tail reads as zeros)
 };
