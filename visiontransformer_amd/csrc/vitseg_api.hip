@@ -180,8 +180,9 @@ int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, c
             // by the SHAPE only (a row's bits must not depend on the batch): patch counts that are whole 64-key tiles and long
             // enough to fill 128-query blocks (512x512: 1024) take attention_f32's tail-free loop, every other length the
             // key-split kernel (tools/attn_small_probe.py, profiles/r05_attn_small_probe.txt: 197 and 785 tokens 1.1-2.7x
-            // faster at every batch; 1025 tokens faster only at batch 1)
-            rc = (s.Np % 64 == 0 && s.N > 400) ? launch_attention_f32(QKV, H, nullptr, batch, s.Np, s.A, DropArgs{}, st)
+            // faster at every batch; 1025 tokens faster only at batch 1; 3137 tokens 1.4x faster at batch 1, 1.06x at 2,
+            // 0.92x at 4: the rows of such a forward end at batch 5)
+            rc = (s.Np % 64 == 0 && s.N > 400 && s.N <= 2048) ? launch_attention_f32(QKV, H, nullptr, batch, s.Np, s.A, DropArgs{}, st)
                                                 : launch_attention_small(QKV, H, batch, s.Np, s.A, st);
             if (rc) return rc;
         }
