@@ -340,6 +340,12 @@ int vitseg_op_gemm_f32(const float* A, const float* W, const float* R, float* C,
                        int epilogue, void* stream);
 int vitseg_op_attention_bwd_f32(const float* qkv, const float* dctx, float* ctx_out, float* lse_out, float* scratch,
                                 float* dqkv, int batch, int num_patches, int num_heads, void* stream);
+/* the same pair for short sequences, as the fp32 training step of the small-batch route runs it (num_patches + 1 <= 400:
+ * the reference's 197 tokens): key-split forward saving the log-sum-exp, then ONE backward launch (dq blocks | dk, dv blocks,
+ * delta formed inside; no scratch).  dropout_p > 0: the counter-based mask of csrc/common.hpp on the probabilities. */
+int vitseg_op_attention_bwd_f32_small(const float* qkv, const float* dctx, float* ctx_out, float* lse_out, float* dqkv,
+                                      int batch, int num_patches, int num_heads, float dropout_p, uint32_t dropout_seed,
+                                      uint32_t dropout_stream, void* stream);
 /* bf16 attention core forward + backward (dropout_p > 0: the counter-based mask of csrc/common.hpp on the attention
  * probabilities, stream id = layer * 8 + 1); ctx_out bf16 [Mt, D], lse_out fp32 [B, A, Np + 1], dqkv bf16 [Mt, 3D].
  * dropmask_words (optional, vitseg_attention_dropmask_bytes; needs num_patches % 128 == 0 and dropout_p > 0): the keep

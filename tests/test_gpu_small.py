@@ -185,6 +185,83 @@ def test_attention_small_is_batch_invariant():
     assert torch.equal(c1[:Np], ctx[Np:2 * Np]) and torch.equal(c1[Np], ctx[B * Np + 1])
 
 
+def _attention_small_fwd_bwd(qkv, dctx, B, Np, A, p=0.0, seed=0xBEEF1234, stream_id=3 * 8 + 1):
+    Mt, D, N = B * Np + B, 64 * A, Np + 1
+    ctx = torch.full((Mt, D), float("nan"), device=DEV)
+    lse = torch.full((B * A * N,), float("nan"), device=DEV)
+    dqkv = torch.full((Mt, 3 * D), float("nan"), device=DEV)
+    _lib.check(_lib.lib().vitseg_op_attention_bwd_f32_small(qkv.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
+                                                            dqkv.data_ptr(), B, Np, A, p, seed, stream_id, _stream()))
+    return ctx, lse, dqkv
+
+
+@pytest.mark.parametrize("B,Np,A,p", [(4, 196, 12, 0.0), (1, 196, 3, 0.0), (2, 49, 2, 0.0), (1, 30, 1, 0.0), (2, 399, 2, 0.0),
+                                      (3, 100, 2, 0.0), (2, 196, 3, 0.1), (1, 127, 2, 0.25)])
+def test_attention_small_forward_and_backward_for_training(B, Np, A, p):
+    """The short-sequence attention pair of the fp32 training step (attention_small.hip with log-sum-exp + dropout,
+    attention_bwd_small.hip: one launch, delta inside) against fp64 autograd of eager_attention_forward
+    (modeling_vit.py:164-189) on the same inputs; dropout through the kernels' counter-based masks regenerated in numpy
+    (tests/dropout_ref.py) and injected into the reference.  Also against the long-sequence kernel pair (p = 0)."""
+    from dropout_ref import Masks
+    D, Mt, N = 64 * A, B * Np + B, Np + 1
+    qkv = _rand(Mt, 3 * D, seed=Np + A, scale=1.2)
+    dctx = _rand(Mt, D, seed=9)
+    seed, stream_id = 0xBEEF1234, 3 * 8 + 1
+    mask = Masks(p, seed, B, Np, A).attn(3, (B, A, N, N)).double() if p else None   # reference token order (CLS first)
+    x = qkv.double().requires_grad_(True)
+    ctx_ref = torch.empty(Mt, D, dtype=torch.float64)
+    lse_ref = torch.empty(B, A, N, dtype=torch.float64)
+    outs = []
+    for b in range(B):
+        r = torch.cat([torch.tensor([B * Np + b]), torch.arange(b * Np, (b + 1) * Np)])
+        q, k, v = [x[r][:, i * D:(i + 1) * D].reshape(N, A, 64).transpose(0, 1) for i in range(3)]
+        sc = q @ k.transpose(-1, -2) * 0.125
+        s = torch.softmax(sc, dim=-1)
+        if mask is not None:
+            s = s * mask[b]
+        o = (s @ v).transpose(0, 1).reshape(N, D)
+        ctx_ref[r] = o.detach()
+        l2 = torch.logsumexp(sc.detach(), dim=-1) * 1.4426950408889634          # [A, N] reference order, log2 domain
+        lse_ref[b] = torch.cat([l2[:, 1:], l2[:, :1]], dim=1)                    # kernel order: CLS last
+        outs.append((o * dctx.double()[r]).sum())
+    torch.stack(outs).sum().backward()
+    qd, dd = qkv.to(DEV), dctx.to(DEV)
+    ctx, lse, dqkv = _attention_small_fwd_bwd(qd, dd, B, Np, A, p, seed, stream_id)
+    assert (ctx.double().cpu() - ctx_ref).abs().max().item() < 2e-5
+    assert (lse.double().cpu().view(B, A, N) - lse_ref).abs().max().item() < 2e-5
+    err = (dqkv.cpu().double() - x.grad).abs().max().item()
+    assert err < 5e-5 * max(1.0, x.grad.abs().max().item()), err
+    if not p:
+        big_ctx, big_lse = torch.empty_like(ctx), torch.empty_like(lse)
+        scr = torch.empty(B * A * N, device=DEV)
+        big = torch.full((Mt, 3 * D), float("nan"), device=DEV)
+        _lib.check(_lib.lib().vitseg_op_attention_bwd_f32(qd.data_ptr(), dd.data_ptr(), big_ctx.data_ptr(), big_lse.data_ptr(),
+                                                          scr.data_ptr(), big.data_ptr(), B, Np, A, _stream()))
+        assert (big - dqkv).abs().max().item() < 5e-5 * max(1.0, x.grad.abs().max().item())
+
+
+def test_attention_small_backward_is_batch_invariant_and_reproducible():
+    """Image 1 of a batch of 4 = that image alone, bit for bit (the key / query split is a function of N only, the partial sums
+    are added in wave order); the same call twice gives the same bits (no atomics).  Dropout on: the masks are keyed by
+    (image, head, query, key), so the lone image is run as image 1 of ITS batch by re-using rows, not re-keyed."""
+    B, Np, A = 4, 196, 12
+    D = 64 * A
+    qkv = _rand(B * Np + B, 3 * D, seed=5, scale=1.2).to(DEV)
+    dctx = _rand(B * Np + B, D, seed=6).to(DEV)
+    c4, l4, g4 = _attention_small_fwd_bwd(qkv, dctx, B, Np, A)
+    c4b, l4b, g4b = _attention_small_fwd_bwd(qkv, dctx, B, Np, A)
+    assert torch.equal(g4, g4b) and torch.equal(c4, c4b) and torch.equal(l4, l4b)
+    one = torch.cat([qkv[Np:2 * Np], qkv[B * Np + 1:B * Np + 2]]).contiguous()
+    done = torch.cat([dctx[Np:2 * Np], dctx[B * Np + 1:B * Np + 2]]).contiguous()
+    c1, l1, g1 = _attention_small_fwd_bwd(one, done, 1, Np, A)
+    assert torch.equal(g1[:Np], g4[Np:2 * Np]) and torch.equal(g1[Np], g4[B * Np + 1])
+    assert torch.equal(l1.view(A, Np + 1), l4.view(B, A, Np + 1)[1])
+    # with dropout: twice the same bits
+    a = _attention_small_fwd_bwd(qkv, dctx, B, Np, A, 0.1)
+    b = _attention_small_fwd_bwd(qkv, dctx, B, Np, A, 0.1)
+    assert all(torch.equal(u, v) for u, v in zip(a, b)) and not torch.equal(a[2], g4)
+
+
 @pytest.mark.parametrize("P,D,L,A", [(16, 768, 2, 12), (16, 512, 2, 8), (8, 512, 1, 8), (16, 1024, 2, 16)])
 def test_small_route_equals_large_route_within_rounding_and_oracle(P, D, L, A):
     """The whole forward at 2 x 224x224, 17 classes: small-batch route against the oracle (the fp32 gate: logits within 1e-3,

@@ -21,10 +21,21 @@ m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg,
 x = torch.from_numpy(synth.make_images(cfg, 4, seed=0)).to(dev)
 y = torch.from_numpy(synth.make_targets(cfg, 4, seed=0, size=224)).to(dev)
 opt = FusedAdam(m.parameters(), lr=1e-5)
-for _ in range(steps):
+def step():
     opt.zero_grad(set_to_none=True)
     loss = m.ce_loss(x, y, grad_scale=1.0)
     loss.backward()
     opt.step()
+    return loss
+
+
+for _ in range(3):
+    loss = step()
 torch.cuda.synchronize()
-print("loss", float(loss))
+t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0.record()
+for _ in range(steps):
+    loss = step()
+t1.record()
+torch.cuda.synchronize()
+print("loss", float(loss), "ms/step %.3f" % (t0.elapsed_time(t1) / steps))

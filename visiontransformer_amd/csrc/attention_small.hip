@@ -25,8 +25,11 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
-__global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int B,
-                                                            int Np, int A) {
+// Training (lse != null and / or dr.thresh != 0): the log2-domain log-sum-exp of every query is saved for the backward and the
+// probabilities are dropped AFTER the normalising sum is taken (torch: dropout(softmax(s))), with the mask of
+// attention_f32.hip -- key (seed, stream, (b A + head) N + query), element = key index.
+__global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                            float* __restrict__ lse, int B, int Np, int A, DropArgs dr) {
     __shared__ __attribute__((aligned(16))) float vt[4][32 * HD];        // per wave: V tile [key][d]
     __shared__ __attribute__((aligned(16))) float om[4][32 * HD];        // per wave: partial output [query][d]
     __shared__ float ml[4][2][32];                                       // per wave: running max / sum per query
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) qreg[4 * c + e] = t[e] * (0.125f * LOG2E);
     }
 
+    const unsigned dkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + q_tok));
     const int KTn = (N + 31) / 32;
     f32x4 kreg[8], vreg[8];
     auto load_tile = [&](int kt) {
@@ -110,6 +114,11 @@ __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restr
         }
         l_run = l_run * alpha + rs;
         m_run = m_new;
+        if (dr.thresh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sacc[r] = drop_keep(dkey, (unsigned)(kt * 32 + kappa(r, lh)), dr.thresh) ? sacc[r] * dr.scale : 0.f;
+        }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -166,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restr
                 acc1[e] += a1[e] * f;
             }
         }
+        if (lse && tok < N && (tid & 7) == 0) lse[((size_t)b * A + head) * N + tok] = M + __builtin_amdgcn_logf(L);
         if (tok < N) {
             const float inv = 1.0f / L;
 #pragma unroll
@@ -182,10 +192,10 @@ __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restr
 
 }  // namespace
 
-int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s) {
+int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s, float* lse, DropArgs dr) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_small: bad arguments");
     const int QT = (Np + 1 + 31) / 32;
-    hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)(B * A * QT)), dim3(256), 0, s, qkv, ctx, B, Np, A);
+    hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)(B * A * QT)), dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr);
     VITSEG_LAUNCH_CHECK("attention_small");
     return VITSEG_OK;
 }

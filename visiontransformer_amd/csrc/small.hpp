@@ -103,7 +103,16 @@ int launch_headfin(const float* partial, size_t split_stride, const float* b0, c
                    int B, int Np, int C, hipStream_t s, float* F_out = nullptr);
 
 // softmax(q k^T / 8) v for short sequences: one block per 32 queries of one (image, head), the four waves split the keys
-int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s);
+// lse (optional): [B, A, Np + 1] log2-domain log-sum-exp per query, saved for the backward; dr: dropout of the probabilities
+int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s, float* lse = nullptr,
+                           DropArgs dr = DropArgs{0, 0, 0, 1.f});
+// its backward (attention_bwd_small.hip): dqkv = (dq | dk | dv) from dctx, the saved qkv / ctx / lse; ONE launch, the
+// blocks of the first half produce dq (32 queries each, the four waves split the keys), those of the second dk / dv
+// (32 keys each, the waves split the queries); delta = rowsum(dctx o ctx) is formed inside
+int launch_attention_bwd_small(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dqkv, int B,
+                               int Np, int A, DropArgs dr, hipStream_t s);
+// the sequence lengths the short-sequence attention kernels take in the TRAINING step (a function of the shape only)
+inline bool attn_small_train(int Np) { return Np + 1 <= 400; }
 
 // true when vitseg_forward takes the small-batch route (fewer than small_max_rows() token rows: SMALL_MAX_ROWS unless the
 // small_max_rows option says otherwise)

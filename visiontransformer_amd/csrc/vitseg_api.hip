@@ -610,6 +610,24 @@ int vitseg_op_attention_bwd_f32(const float* qkv, const float* dctx, float* ctx_
                                     (hipStream_t)stream);
 }
 
+// the same pair for short sequences (small.hpp): key-split forward saving the log-sum-exp, one-launch backward
+int vitseg_op_attention_bwd_f32_small(const float* qkv, const float* dctx, float* ctx_out, float* lse_out, float* dqkv,
+                                      int batch, int num_patches, int num_heads, float dropout_p, uint32_t dropout_seed,
+                                      uint32_t dropout_stream, void* stream) {
+    VITSEG_CHECK_ARG(qkv && dctx && ctx_out && lse_out && dqkv, VITSEG_EINVAL, "attention_bwd_small: null pointer");
+    VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "attention_bwd_small: dropout_p %f", dropout_p);
+    DropArgs d{0, 0, 0, 1.f};
+    if (dropout_p > 0.f) {
+        d.thresh = (unsigned)((double)dropout_p * 65536.0 + 0.5);
+        if (d.thresh == 0) d.thresh = 1;
+        d.seed = dropout_seed;
+        d.stream = dropout_stream;
+        d.scale = (float)(1.0 / (1.0 - (double)dropout_p));
+    }
+    if (int rc = launch_attention_small(qkv, ctx_out, batch, num_patches, num_heads, (hipStream_t)stream, lse_out, d)) return rc;
+    return launch_attention_bwd_small(qkv, ctx_out, dctx, lse_out, dqkv, batch, num_patches, num_heads, d, (hipStream_t)stream);
+}
+
 // bf16 forward (saving the log-sum-exp, optional attention-probability dropout) + backward of the attention core
 size_t vitseg_attention_dropmask_bytes(int batch, int num_patches, int num_heads) {
     return batch > 0 && num_heads > 0 && num_patches > 0 && num_patches % 128 == 0
