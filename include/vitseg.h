@@ -365,6 +365,15 @@ int vitseg_op_attention_bwd_bf16(const void* qkv, const void* dctx, void* ctx_ou
 size_t vitseg_op_layernorm_bwd_scratch_floats(int rows, int D);
 int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, const float* dres_in, float* dres_out,
                                 float* dw, float* db, float* scratch, int rows, int D, float eps, void* stream);
+/* the form the fp32 training step of the small-batch route uses (same arithmetic and bits for dres_out / dw / db): g arrives as
+ * g_splits K-chunk slabs, g = slab 0 + slab 1 + ... (slab s at g + s * g_stride floats; 1 = plain); br_dbias != NULL: also the
+ * gradient entering the NEXT dropped residual branch of the backward walk -- br_out = mask * dres_out (written only when
+ * dropout_p > 0; hidden dropout of csrc/common.hpp with the given stream id), br_dbias [D] = its column sums (= column sums of
+ * dres_out when dropout_p == 0): that branch's bias gradient.  scratch: vitseg_op_layernorm_bwd_scratch_floats(rows, D). */
+int vitseg_op_layernorm_bwd_f32_small(const float* x, const float* w, const float* g, size_t g_stride, int g_splits,
+                                      const float* dres_in, float* dres_out, float* dw, float* db, float* scratch, int rows,
+                                      int D, float eps, float* br_out, float* br_dbias, float dropout_p, uint32_t dropout_seed,
+                                      uint32_t dropout_stream, void* stream);
 
 /* ---- measurement hooks (bench.py's roofline object) ----
  * While enabled, vitseg_forward brackets every kernel launch of the hot path with a pair of

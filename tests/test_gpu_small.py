@@ -185,6 +185,51 @@ def test_attention_small_is_batch_invariant():
     assert torch.equal(c1[:Np], ctx[Np:2 * Np]) and torch.equal(c1[Np], ctx[B * Np + 1])
 
 
+@pytest.mark.parametrize("rows,D,splits,p", [(788, 768, 6, 0.1), (788, 768, 1, 0.0), (197, 192, 3, 0.25), (3140, 512, 6, 0.0),
+                                             (50, 1024, 6, 0.1), (784, 768, 1, 0.1)])
+def test_layernorm_backward_small_slabs_and_branch_outputs(rows, D, splits, p):
+    """LayerNorm backward as the fp32 training step of the small-batch route runs it (backward.hip:layernorm_bwd_small_kernel):
+    same bits as vitseg_op_layernorm_bwd_f32 on the chunk-order sum of the slabs; the next branch's dropped gradient equals
+    the counter-based mask (tests/dropout_ref.py) times dres_out, and br_dbias its column sums."""
+    from dropout_ref import Masks
+    x = (_rand(rows, D, seed=1, scale=2.0) + 0.3).to(DEV)
+    w = (_rand(D, seed=2) + 1.0).to(DEV)
+    slabs = _rand(splits, rows, D, seed=4).to(DEV)
+    dres = _rand(rows, D, seed=5).to(DEV)
+    g = slabs[0].clone()
+    for s_ in range(1, splits):
+        g = g + slabs[s_]
+    n_scr = _lib.lib().vitseg_op_layernorm_bwd_scratch_floats(rows, D)
+    ref_out, ref_dw, ref_db = torch.empty(rows, D, device=DEV), torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    scratch = torch.empty(n_scr, device=DEV)
+    _lib.check(_lib.lib().vitseg_op_layernorm_bwd_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), dres.data_ptr(), ref_out.data_ptr(),
+                                                      ref_dw.data_ptr(), ref_db.data_ptr(), scratch.data_ptr(), rows, D, 1e-12, _stream()))
+    out, dw, db = torch.full((rows, D), float("nan"), device=DEV), torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    br = torch.full((rows, D), float("nan"), device=DEV)
+    dbias = torch.full((D,), float("nan"), device=DEV)
+    seed, layer, site = 0x1234ABCD, 5, 2
+    _lib.check(_lib.lib().vitseg_op_layernorm_bwd_f32_small(
+        x.data_ptr(), w.data_ptr(), slabs.data_ptr(), rows * D, splits, dres.data_ptr(), out.data_ptr(), dw.data_ptr(), db.data_ptr(),
+        scratch.data_ptr(), rows, D, 1e-12, br.data_ptr() if p else None, dbias.data_ptr(), p, seed, layer * 8 + site, _stream()))
+    assert torch.equal(out, ref_out) and torch.equal(dw, ref_dw) and torch.equal(db, ref_db)
+    if p:
+        # Masks.rows works in the reference's [B, N, D] layout; one "image" of rows - 1 patches + CLS last = rows in kernel order
+        mk = Masks(p, seed, 1, rows - 1, 1)
+        m = mk.rows(layer, site, (1, rows, D))[0]                  # reference order: CLS (kernel row rows - 1) first
+        m = torch.cat([m[1:], m[:1]]).to(DEV)
+        assert torch.equal(br, out * m)
+        want = br.double().sum(0)
+    else:
+        want = out.double().sum(0)
+    assert (dbias.double() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+    # without the branch outputs: nothing else changes
+    out2 = torch.empty_like(out)
+    _lib.check(_lib.lib().vitseg_op_layernorm_bwd_f32_small(
+        x.data_ptr(), w.data_ptr(), slabs.data_ptr(), rows * D, splits, None, out2.data_ptr(), dw.data_ptr(), db.data_ptr(),
+        scratch.data_ptr(), rows, D, 1e-12, None, None, 0.0, 0, 0, _stream()))
+    assert torch.equal(dw, ref_dw) and torch.equal(db, ref_db) and (out2 - (ref_out - dres)).abs().max().item() < 1e-5
+
+
 def _attention_small_fwd_bwd(qkv, dctx, B, Np, A, p=0.0, seed=0xBEEF1234, stream_id=3 * 8 + 1):
     Mt, D, N = B * Np + B, 64 * A, Np + 1
     ctx = torch.full((Mt, D), float("nan"), device=DEV)

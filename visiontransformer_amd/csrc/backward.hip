@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "small.hpp"
 
 namespace vitseg {
 namespace {
@@ -258,6 +259,143 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_finish_kernel(const float*
         else if (col < 2 * D) db[col - D] = v;
         else dbr[col - 2 * D] = v;
     }
+}
+
+// ---- LayerNorm backward of the small-batch fp32 training step (small.hpp) ----------------------------------------
+// The arithmetic, the row-to-wave assignment and the partial-sum order of layernorm_bwd_kernel<NV, float, false> (same bits for
+// dx / dw / db), with what the small route hangs on it so that no separate pass re-reads the rows:
+//   * g may arrive as K-chunk slabs of the activation-gradient GEMM (gemm_f32s SE_PARTIAL): g = slab 0 + slab 1 + ... in
+//     chunk order (launch_slabsum's order), summed here;
+//   * the gradient that enters the NEXT dropped residual branch of the backward walk, mask * dres_out (hidden dropout of that
+//     branch; thresh 0: dres_out itself, nothing written), and its column sums = that branch's bias gradient (third partial
+//     set) -- the fp32 form of the BR mode above.
+// One wave per row, every load of the row issued up front (788 rows: latency, not bandwidth).
+struct LnbSmall {
+    const float* x;
+    const float* w;
+    const float* g;
+    size_t g_stride;
+    int g_splits;
+    const float* dres_in;
+    float* dres_out;
+    float* partial;
+    int rows, D, sets;
+    float eps;
+    float* br_out;
+    DropArgs br_drop;
+};
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const LnbSmall p) {
+    __shared__ float red[3][4][NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = p.D, nv = D >> 2;
+    f32x4 wv[NV], dw[NV], db[NV], dbr[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        wv[i] = ((const f32x4*)p.w)[min(lane + 64 * i, nv - 1)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dw[i][e] = db[i][e] = dbr[i][e] = 0.f;
+    }
+    const int row_begin = (int)((long long)blockIdx.x * p.rows / (int)gridDim.x);
+    const int row_end = (int)((long long)(blockIdx.x + 1) * p.rows / (int)gridDim.x);
+    for (int row = row_begin + wave; row < row_end; row += 4) {   // wave-uniform
+        f32x4 xv[NV], gv[NV], dv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = min(lane + 64 * i, nv - 1);
+            xv[i] = ((const f32x4*)(p.x + (size_t)row * D))[c];
+            gv[i] = ((const f32x4*)(p.g + (size_t)row * D))[c];
+            if (p.dres_in) dv[i] = ((const f32x4*)(p.dres_in + (size_t)row * D))[c];
+        }
+        constexpr int G = NV <= 3 ? 5 : 2;
+        for (int s0 = 1; s0 < p.g_splits; s0 += G) {
+            f32x4 t[G][NV];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const f32x4* ps = (const f32x4*)(p.g + (size_t)min(s0 + u, p.g_splits - 1) * p.g_stride + (size_t)row * D);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) t[u][i] = ps[min(lane + 64 * i, nv - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+                if (s0 + u < p.g_splits) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gv[i][e] += t[u][i][e];
+                }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float t = (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+            s += (lane + 64 * i < nv) ? t : 0.f;
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[i][e] -= mean;
+                t = fmaf(xv[i][e], xv[i][e], t);
+            }
+            q += (lane + 64 * i < nv) ? t : 0.f;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + p.eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bool ok = lane + 64 * i < nv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[i][e] *= rstd;  // xhat
+                const float gw = gv[i][e] * wv[i][e];
+                if (ok) {
+                    s1 += gw;
+                    s2 = fmaf(gw, xv[i][e], s2);
+                    dw[i][e] = fmaf(gv[i][e], xv[i][e], dw[i][e]);
+                    db[i][e] += gv[i][e];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+        const unsigned bkey = drop_key(p.br_drop.seed, p.br_drop.stream, (unsigned)row);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (p.dres_in) o = dv[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += rstd * (gv[i][e] * wv[i][e] - c1 - xv[i][e] * c2);
+                ((f32x4*)(p.dres_out + (size_t)row * D))[c] = o;
+                if (p.sets == 3) {
+                    if (p.br_drop.thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = drop_keep(bkey, (unsigned)(4 * c + e), p.br_drop.thresh) ? o[e] * p.br_drop.scale : 0.f;
+                        ((f32x4*)(p.br_out + (size_t)row * D))[c] = o;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dbr[i][e] += o[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[0][wave][(lane + 64 * i) * 4 + e] = dw[i][e];
+            red[1][wave][(lane + 64 * i) * 4 + e] = db[i][e];
+            red[2][wave][(lane + 64 * i) * 4 + e] = dbr[i][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256)
+        for (int k = 0; k < p.sets; ++k)
+            p.partial[((size_t)blockIdx.x * p.sets + k) * D + c] = (red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c]);
 }
 
 // ---- transposed bilinear upsample: G[B,C,S,S] -> dZ[B,C,g,g] -----------------------------------
@@ -575,35 +713,37 @@ int launch_colsum_finish_fused(const void* tail_rows, int tail, int chunk0, floa
     VITSEG_LAUNCH_CHECK("colsum_finish");
     return VITSEG_OK;
 }
-// Few rows (the reference's batch 4 x 224x224: 788): one launch -- a block owns 16 columns, its 16 row groups walk the rows
-// 16 apart (64-byte pieces of a row per group), LDS combines the groups in group order -- instead of the partial + finish pair
-// (7 + 5 us, fifty times per training step).
-__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ X, float* __restrict__ out, int M, int N, int ld) {
-    __shared__ float red[16][17];
+// Few rows (the reference's batch 4 x 224x224: 788): one launch -- a block owns 16 columns, its 64 row groups walk the rows
+// 64 apart (64-byte pieces of a row per group, four independent sums per group: 13 rows = 4 dependent loads at 788 rows),
+// LDS combines the groups in group order -- instead of the partial + finish pair (7 + 5 us, many times per training step).
+__global__ __launch_bounds__(1024) void colsum_small_kernel(const float* __restrict__ X, float* __restrict__ out, int M, int N, int ld) {
+    __shared__ float red[64][17];
     const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int col = blockIdx.x * 16 + c;
-    float s0 = 0.f, s1 = 0.f;
-    if (col < N) {
-        int r = rg;
-        for (; r + 16 < M; r += 32) {
-            s0 += X[(size_t)r * ld + col];
-            s1 += X[(size_t)(r + 16) * ld + col];
-        }
-        if (r < M) s0 += X[(size_t)r * ld + col];
+    const int col = min((int)blockIdx.x * 16 + c, N - 1);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = rg;
+    for (; r + 192 < M; r += 256) {
+        s0 += X[(size_t)r * ld + col];
+        s1 += X[(size_t)(r + 64) * ld + col];
+        s2 += X[(size_t)(r + 128) * ld + col];
+        s3 += X[(size_t)(r + 192) * ld + col];
     }
-    red[rg][c] = s0 + s1;
+    if (r < M) s0 += X[(size_t)r * ld + col];
+    if (r + 64 < M) s1 += X[(size_t)(r + 64) * ld + col];
+    if (r + 128 < M) s2 += X[(size_t)(r + 128) * ld + col];
+    red[rg][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (rg == 0 && col < N) {
+    if (rg == 0 && (int)blockIdx.x * 16 + c < N) {
         float t = red[0][c];
 #pragma unroll
-        for (int g = 1; g < 16; ++g) t += red[g][c];
+        for (int g = 1; g < 64; ++g) t += red[g][c];
         out[col] = t;
     }
 }
 
 int launch_colsum(const void* X, int x_is_bf16, float* out, float* scratch, int M, int N, int ld, hipStream_t s) {
     if (!x_is_bf16 && M <= 4096) {
-        hipLaunchKernelGGL(colsum_small_kernel, dim3((N + 15) / 16), dim3(256), 0, s, (const float*)X, out, M, N, ld);
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((N + 15) / 16), dim3(1024), 0, s, (const float*)X, out, M, N, ld);
         VITSEG_LAUNCH_CHECK("colsum_small");
         return VITSEG_OK;
     }
@@ -694,6 +834,26 @@ int launch_layernorm_bwd(const float* x, const float* w, const void* g, int g_is
     const int sets = br_out ? 3 : 2;
     hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((sets * D + 63) / 64), dim3(1024), 0, s, scratch, dw, db,
                        br_dbias, blocks, D, sets);
+    VITSEG_LAUNCH_CHECK("layernorm_bwd_finish");
+    return VITSEG_OK;
+}
+
+int launch_layernorm_bwd_small(const float* x, const float* w, const float* g, size_t g_stride, int g_splits,
+                               const float* dres_in, float* dres_out, float* dw, float* db, float* scratch, int rows, int D,
+                               float eps, hipStream_t s, float* br_out, DropArgs br_drop, float* br_dbias) {
+    VITSEG_CHECK_ARG(x && w && g && dres_out && dw && db && scratch && rows > 0 && g_splits >= 1, VITSEG_EINVAL, "layernorm_bwd_small: bad arguments");
+    VITSEG_CHECK_ARG(D % 4 == 0 && D <= 1024, VITSEG_ESHAPE, "layernorm_bwd_small: D=%d must be a multiple of 4, <= 1024", D);
+    VITSEG_CHECK_ARG(!br_drop.thresh || (br_out && br_dbias), VITSEG_EINVAL, "layernorm_bwd_small: a dropped branch needs br_out and br_dbias");
+    const int nvl = (D / 4 + 63) / 64;
+    const int blocks = lnb_blocks(rows, D);
+    LnbSmall p{x, w, g, g_stride, g_splits, dres_in, dres_out, scratch, rows, D, br_dbias ? 3 : 2, eps, br_out, br_drop};
+    if (nvl <= 1) hipLaunchKernelGGL(layernorm_bwd_small_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
+    else if (nvl <= 2) hipLaunchKernelGGL(layernorm_bwd_small_kernel<2>, dim3(blocks), dim3(256), 0, s, p);
+    else if (nvl <= 3) hipLaunchKernelGGL(layernorm_bwd_small_kernel<3>, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(layernorm_bwd_small_kernel<4>, dim3(blocks), dim3(256), 0, s, p);
+    VITSEG_LAUNCH_CHECK("layernorm_bwd_small");
+    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((p.sets * D + 63) / 64), dim3(1024), 0, s, scratch, dw, db, br_dbias,
+                       blocks, D, p.sets);
     VITSEG_LAUNCH_CHECK("layernorm_bwd_finish");
     return VITSEG_OK;
 }

@@ -111,6 +111,14 @@ int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, h
 // (32 keys each, the waves split the queries); delta = rowsum(dctx o ctx) is formed inside
 int launch_attention_bwd_small(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dqkv, int B,
                                int Np, int A, DropArgs dr, hipStream_t s);
+// LayerNorm backward of the small-batch training step (backward.hip): layernorm_bwd's arithmetic with g taken as g_splits K-chunk
+// slabs (summed in chunk order), and -- br_dbias != null -- the gradient entering the next dropped residual branch,
+// br_out = mask * dres_out (written only when br_drop.thresh != 0; otherwise the branch reads dres_out), with its column sums
+// br_dbias = that branch's bias gradient.  scratch: layernorm_bwd_scratch_floats(rows, D).
+int launch_layernorm_bwd_small(const float* x, const float* w, const float* g, size_t g_stride, int g_splits,
+                               const float* dres_in, float* dres_out, float* dw, float* db, float* scratch, int rows, int D,
+                               float eps, hipStream_t s, float* br_out = nullptr, DropArgs br_drop = DropArgs{0, 0, 0, 1.f},
+                               float* br_dbias = nullptr);
 // the sequence lengths the short-sequence attention kernels take in the TRAINING step (a function of the shape only)
 inline bool attn_small_train(int Np) { return Np + 1 <= 400; }
 

@@ -672,6 +672,23 @@ int vitseg_op_layernorm_bwd_f32(const float* x, const float* w, const float* g, 
                                 float* dw, float* db, float* scratch, int rows, int D, float eps, void* stream) {
     return launch_layernorm_bwd(x, w, g, 0, dres_in, dres_out, dw, db, scratch, rows, D, eps, (hipStream_t)stream);
 }
+// the small-batch training step's form: g as K-chunk slabs, the next branch's dropped gradient + bias gradient (small.hpp)
+int vitseg_op_layernorm_bwd_f32_small(const float* x, const float* w, const float* g, size_t g_stride, int g_splits,
+                                      const float* dres_in, float* dres_out, float* dw, float* db, float* scratch, int rows,
+                                      int D, float eps, float* br_out, float* br_dbias, float dropout_p, uint32_t dropout_seed,
+                                      uint32_t dropout_stream, void* stream) {
+    VITSEG_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, VITSEG_EINVAL, "layernorm_bwd_small: dropout_p %f", dropout_p);
+    DropArgs d{0, 0, 0, 1.f};
+    if (dropout_p > 0.f) {
+        d.thresh = (unsigned)((double)dropout_p * 65536.0 + 0.5);
+        if (d.thresh == 0) d.thresh = 1;
+        d.seed = dropout_seed;
+        d.stream = dropout_stream;
+        d.scale = 1.0f / (1.0f - dropout_p);
+    }
+    return launch_layernorm_bwd_small(x, w, g, g_stride, g_splits, dres_in, dres_out, dw, db, scratch, rows, D, eps,
+                                      (hipStream_t)stream, br_out, d, br_dbias);
+}
 
 int vitseg_op_attention_bf16(const void* qkv, void* ctx, int batch, int num_patches, int num_heads, void* stream) {
     return launch_attention_bf16(qkv, ctx, nullptr, batch, num_patches, num_heads, DropArgs{}, (hipStream_t)stream);
