@@ -9,7 +9,7 @@
 // Why not attention_bwd_f32.hip: its blocks own 128 tokens and walk the other side in a serial loop -- at N = 197 and batch 4
 // that is 96 blocks on 256 CUs with four dependent 64-token tiles each (43 + 54 us per layer, plus the delta launch:
 // profiles/r05_train_b4_224_f32_kernel_stats_after.csv).  Here the work is cut the way attention_small.hip cuts the forward:
-//   * ONE launch; the first B A ceil(N / 32) blocks produce dQ for 32 queries each, the second half dK / dV for 32 keys each;
+//   * ONE launch; the first B A ceil(N / 32) blocks produce dK / dV for 32 keys each, the second half dQ for 32 queries each;
 //   * the four waves of a block hold the SAME 32 lane-side tokens and split the OTHER side in 32-token pieces (wave w takes
 //     pieces w, w + 4, ...: 2 of the 7 at N = 197); the four partial sums are added through LDS in wave order -- a fixed order,
 //     and the split is a function of N only (batch invariant, no atomics);
@@ -77,23 +77,24 @@ __device__ __forceinline__ void dq_block(const BwdSmall& p, int b, int head, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
-    float* kw = lds + wave * WAVE_FLOATS;   // this wave's K piece [key][d]
+    float* kw = lds + wave * WAVE_FLOATS;   // this wave's K piece [key][d], rows 68 floats apart
+    constexpr int KS = HD + 4;              // (a lane writes 16-byte pieces of ITS key's row: 16 lanes x 4 banks = all 64 banks)
     const int KH = (N + 31) / 32;
-    for (int kh = wave; kh < KH; kh += 4) {
-        // row form straight from global memory (lane (li, lh) = key li, pieces 8 cc + 4 lh); the piece again as whole 256-byte
-        // rows for the transposed read (instruction cc moves keys 4 cc .. 4 cc + 3: coalesced, conflict-free LDS writes)
+    // row form straight from global memory: lane (li, lh) = key li of the piece, pieces 8 cc + 4 lh of its K and V rows
+    f32x4 kf[8], vf[8];
+    auto load_piece = [&](int kh) {
         const size_t krow = token_row(min(kh * 32 + li, N - 1)) * ld + 4 * lh;
-        f32x4 kf[8], vf[8];
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
             kf[cc] = *(const f32x4*)(kbase + krow + 8 * cc);
             vf[cc] = *(const f32x4*)(vbase + krow + 8 * cc);
         }
+    };
+    if (wave < KH) load_piece(wave);
+    for (int kh = wave; kh < KH; kh += 4) {
+        // the K piece once more in LDS for the transposed read of the dQ product (in order behind the previous piece's reads)
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            const f32x4 t = *(const f32x4*)(kbase + token_row(min(kh * 32 + 4 * cc + (lane >> 4), N - 1)) * ld + 4 * (lane & 15));
-            *(f32x4*)(kw + (4 * cc + (lane >> 4)) * HD + 4 * (lane & 15)) = t;
-        }
+        for (int cc = 0; cc < 8; ++cc) *(f32x4*)(kw + li * KS + 8 * cc + 4 * lh) = kf[cc];
         // S^T and dP^T: [key][query]
         f32x16 st, dp;
 #pragma unroll
@@ -105,10 +106,12 @@ __device__ __forceinline__ void dq_block(const BwdSmall& p, int b, int head, int
                 st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cc][e], qreg[4 * cc + e], st, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cc][e], doreg[4 * cc + e], dp, 0, 0, 0);
             }
+        const int key0 = kh * 32;
+        if (kh + 4 < KH) load_piece(kh + 4);   // the next piece's rows in flight under the dS arithmetic and the dQ products
         // dS^T = P o (keep dP - delta); keys beyond N contribute nothing
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = kh * 32 + kappa(r, lh);
+            const int key = key0 + kappa(r, lh);
             const float pv = key < N ? __builtin_amdgcn_exp2f(st[r] - lse_q) : 0.f;
             float dpr = dp[r];
             if (p.dr.thresh) dpr = drop_keep(dkey, (unsigned)key, p.dr.thresh) ? dpr * p.dr.scale : 0.f;
@@ -117,7 +120,7 @@ __device__ __forceinline__ void dq_block(const BwdSmall& p, int b, int head, int
         // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const float k0 = kw[kappa(s, lh) * HD + li], k1 = kw[kappa(s, lh) * HD + 32 + li];
+            const float k0 = kw[kappa(s, lh) * KS + li], k1 = kw[kappa(s, lh) * KS + 32 + li];
             dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0, st[s], dq[0], 0, 0, 0);
             dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1, st[s], dq[1], 0, 0, 0);
         }
@@ -279,8 +282,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const BwdSmall p
     const int t = (int)blockIdx.x < half ? (int)blockIdx.x : (int)blockIdx.x - half;
     const int bh = t / T, rt = t - bh * T;
     const int b = bh / p.A, head = bh - b * p.A;
-    if ((int)blockIdx.x < half) dq_block(p, b, head, rt, lds);
-    else dkv_block(p, b, head, rt, lds);
+    // the longer dk / dv blocks first: the dq blocks fill the slots (two blocks per CU) as they come free
+    if ((int)blockIdx.x < half) dkv_block(p, b, head, rt, lds);
+    else dq_block(p, b, head, rt, lds);
 }
 
 }  // namespace

@@ -107,8 +107,8 @@ int launch_headfin(const float* partial, size_t split_stride, const float* b0, c
 int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s, float* lse = nullptr,
                            DropArgs dr = DropArgs{0, 0, 0, 1.f});
 // its backward (attention_bwd_small.hip): dqkv = (dq | dk | dv) from dctx, the saved qkv / ctx / lse; ONE launch, the
-// blocks of the first half produce dq (32 queries each, the four waves split the keys), those of the second dk / dv
-// (32 keys each, the waves split the queries); delta = rowsum(dctx o ctx) is formed inside
+// blocks of the first half produce dk / dv (32 keys each, the four waves split the queries), those of the second dq
+// (32 queries each, the waves split the keys); delta = rowsum(dctx o ctx) is formed inside
 int launch_attention_bwd_small(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dqkv, int B,
                                int Np, int A, DropArgs dr, hipStream_t s);
 // LayerNorm backward of the small-batch training step (backward.hip): layernorm_bwd's arithmetic with g taken as g_splits K-chunk
