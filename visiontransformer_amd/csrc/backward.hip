@@ -503,10 +503,11 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 
 // ---- seg_head.2 (1x1 conv) backward + ReLU backward --------------------------------------------
 // dFpre[m][j] = (F[m][j] > 0) * sum_c dZ[b,c,t] W2[c][j];  dW2[c][j] = sum_m dZ[b,c,t] F[m][j].
-// Thread = mid channel j, block = 64 rows; partial dW2 to partial[block][C][256].  C <= 32.
+// Thread = mid channel j, block = rpb rows (64; 8 for the few rows of the reference's batch: 98 blocks of 8 dependent rows
+// instead of 13 of 64 -- 128 us at 784 rows); partial dW2 to partial[block][C][256].  C <= 32.
 __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float* __restrict__ dZ, const float* __restrict__ F,
                                                           const float* __restrict__ W2, float* __restrict__ dFpre,
-                                                          float* __restrict__ partial, int B, int Np, int C) {
+                                                          float* __restrict__ partial, int B, int Np, int C, int rpb) {
     const int j = threadIdx.x;
     float w[32], dw[32];
     for (int c = 0; c < C; ++c) {
@@ -514,8 +515,8 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float* __restric
         dw[c] = 0.f;
     }
     const int M = B * Np;
-    for (int it = 0; it < 64; ++it) {
-        const int m = blockIdx.x * 64 + it;
+    for (int it = 0; it < rpb; ++it) {
+        const int m = blockIdx.x * rpb + it;
         if (m >= M) break;
         const int b = m / Np, t = m - b * Np;
         const float f = F[(size_t)m * MID + j];
@@ -868,12 +869,16 @@ int launch_upsample_bwd(const float* G, float* dZ, int B, int C, int g, int S, h
     return VITSEG_OK;
 }
 
-size_t head1x1_bwd_scratch_floats(int B, int Np, int C) { return (size_t)((B * Np + 63) / 64) * C * MID; }
+static int head1x1_rpb(int M) { return M < 16384 ? 8 : 64; }   // a function of the row count only (the order of the dW2 sum)
+size_t head1x1_bwd_scratch_floats(int B, int Np, int C) {
+    const int M = B * Np, rpb = head1x1_rpb(M);
+    return (size_t)((M + rpb - 1) / rpb) * C * MID;
+}
 int launch_head1x1_bwd(const float* dZ, const float* F, const float* W2, float* dFpre, float* dW2, float* db2,
                        float* scratch, int B, int Np, int C, hipStream_t s) {
     VITSEG_CHECK_ARG(C <= 32, VITSEG_ESHAPE, "training supports at most 32 classes (got %d)", C);
-    const int blocks = (B * Np + 63) / 64;
-    hipLaunchKernelGGL(head1x1_bwd_kernel, dim3(blocks), dim3(256), 0, s, dZ, F, W2, dFpre, scratch, B, Np, C);
+    const int rpb = head1x1_rpb(B * Np), blocks = (B * Np + rpb - 1) / rpb;
+    hipLaunchKernelGGL(head1x1_bwd_kernel, dim3(blocks), dim3(256), 0, s, dZ, F, W2, dFpre, scratch, B, Np, C, rpb);
     VITSEG_LAUNCH_CHECK("head1x1_bwd");
     // scratch is [blocks][C*256]: column sums over the blocks
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C * MID + 63) / 64), dim3(1024), 0, s, scratch, dW2, blocks, C * MID);
