@@ -115,6 +115,22 @@ def test_layernorm_backward_keeps_three_blocks_per_cu(tmp_path):
     assert found >= 1, "no layernorm_bwd_kernel<3, ...> instantiation found"
 
 
+def test_small_attention_backward_fits_two_blocks_per_cu(tmp_path):
+    """attention_bwd_small.hip: one launch, two co-resident 256-thread blocks per CU (__launch_bounds__(256, 2): 256 registers
+    per lane, 66 KiB of LDS).  Its dk / dv half keeps 128 accumulator + operand registers across the loop; the loop-invariant
+    LDS addresses are formed where they are used (opaque lane coordinates) so that they are not kept in ~50 more -- which
+    spilled 26 registers to scratch.  Nothing at run time reports a spill; this does."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    text = _asm("attention_bwd_small.hip", [], tmp_path)
+    body = re.search(r"\.amdhsa_kernel (\S*attn_bwd_small_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S).group(2)
+    nv = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+    scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
+    assert nv <= 256 and scratch == 0 and lds <= 80 * 1024, (nv, scratch, lds)
+    assert "scratch_load" not in text and "scratch_store" not in text
+
+
 def _vgprs(text):
     """VGPR numbers an operand string mentions (v7, v[4:7]; not a[..] / s[..])."""
     regs = set()
