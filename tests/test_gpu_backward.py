@@ -105,15 +105,19 @@ def _build(g: Golden, precision="fp32"):
     return lm
 
 
+@pytest.mark.parametrize("route", ["small", "large"])
 @pytest.mark.parametrize("name", [c for c in CASES if Golden(c).has("grad.seg_head.2.weight")])
-def test_training_step_matches_reference_gradients(name):
-    """LightningViTModel.training_step + backward + one Adam(lr=1e-5) step vs the real reference class."""
+def test_training_step_matches_reference_gradients(name, route):
+    """LightningViTModel.training_step + backward + one Adam(lr=1e-5) step vs the real reference class -- through the
+    small-batch route of the fp32 step (csrc/small.hpp: every fixture is that small) and, with the `no_small` switch held over
+    forward and backward, through the large-batch kernels (what an fp32 step of 16 384 token rows or more runs)."""
     g = Golden(name)
     lm = _build(g).train()
     opt = lm.configure_optimizers()
-    loss = lm.training_step((g.images().to(DEV), g.targets().to(DEV)), 0)
-    assert abs(float(loss) - float(g.z["train.loss"][0])) < 2e-6
-    loss.backward()
+    with _lib.option("no_small", int(route == "large")):
+        loss = lm.training_step((g.images().to(DEV), g.targets().to(DEV)), 0)
+        assert abs(float(loss) - float(g.z["train.loss"][0])) < 2e-6
+        loss.backward()
     views = {k: v for k, v in zip(lm.model.named_views().keys(),
                                   __import__("visiontransformer_amd.params", fromlist=["x"]).arena_views(
                                       g.cfg, lm.model.arena.grad).values())}
@@ -397,18 +401,21 @@ def _dropout_case():
     return cfg, sd, x, y
 
 
-def test_dropout_training_step_matches_oracle_with_identical_masks():
+@pytest.mark.parametrize("route", ["small", "large"])
+def test_dropout_training_step_matches_oracle_with_identical_masks(route):
     """Train-mode dropout (p = 0.1 at the four HF sites).  torch's RNG stream cannot be matched, but the build's
     masks are a pure function of (seed, layer, site, element): tests/dropout_ref.py regenerates them in numpy and
-    injects them into the oracle, so forward AND backward can be compared exactly like the p = 0 case."""
+    injects them into the oracle, so forward AND backward can be compared exactly like the p = 0 case.  Both routes of the
+    fp32 step (small-batch kernels / `no_small`: large-batch kernels) draw the same masks."""
     from dropout_ref import Masks
     from visiontransformer_amd.params import arena_views
     cfg, sd, x, y = _dropout_case()
     m = ViTSegmentationModel(3, 16, 192, 2, 3, image_size=96, dropout=0.1, device=DEV).train()
     m.load_state_dict(sd)
     seed64 = (m.dropout_seed * 0x9E3779B97F4A7C15 + 1 * 0x100000001B3 + 0) & (2 ** 64 - 1)  # first training forward
-    loss = m.ce_loss(x.to(DEV), y.to(DEV))
-    loss.backward()
+    with _lib.option("no_small", int(route == "large")):
+        loss = m.ce_loss(x.to(DEV), y.to(DEV))
+        loss.backward()
     masks = Masks(0.1, seed64, 2, cfg.num_patches, 3)
     assert abs(float((masks.rows(0, 0, (2, 37, 192)) > 0).float().mean()) - 0.9) < 0.01
     leaf = {k: v.double().requires_grad_(True) for k, v in sd.items()}
