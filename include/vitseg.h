@@ -186,6 +186,13 @@ int vitseg_op_wgrad_f32_small(const float* dY, const float* X, float* dW, int M,
  * 8 words per launched block) and `lds_pad` extra bytes of LDS per block (limits the blocks per CU).  tools/small_stamps.py. */
 int vitseg_dbg_linear_f32_small(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epilogue,
                                 unsigned long long* stamps, int lds_pad, void* stream);
+/* the 16-bit form of that route's linears (vitseg_forward takes it for VITSEG_BF16 / VITSEG_F16 below 16 384 token rows when the
+ * sequence length is one of the key-split attention kernel's): A [M, K] and W [N, K] as raw bf16 (f16 = 0) or IEEE half bits, the
+ * same kernels on v_mfma_f32_32x32x16_*, fp32 accumulate.  epilogue 0: C fp32 = acc + bias; 1: C 16-bit = gelu(acc + bias) (the
+ * next GEMM's operand); 2 (any shape): the vitseg_small_splits(N, K) chunk slabs into scratch, C fp32 = chunk sums in chunk order
+ * + bias (scratch: (splits + 1) * M * N floats). */
+int vitseg_op_linear_h16_small(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int epilogue, int f16,
+                               float* scratch, size_t scratch_floats, void* stream);
 /* attention core for short sequences (same arguments and layout as vitseg_op_attention_f32) */
 int vitseg_op_attention_f32_small(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream);
 /* bf16 operands (A, W as raw bf16 bits), fp32 accumulate; bias and R fp32.  C is bf16 for epilogues 0/1

@@ -143,13 +143,16 @@ TOL_LOGITS_BF16 = 3e-2
 TOL_LOGITS_16 = {"bf16": TOL_LOGITS_BF16, "fp16": 1e-3}
 
 
+@pytest.mark.parametrize("route", ["small", "large"])
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", [c for c in CASES if "sat" not in c])
-def test_forward_bf16_close_to_golden(name, precision):
+def test_forward_bf16_close_to_golden(name, precision, route):
+    """The 16-bit modes through both routes: the small-batch route (16-bit operands on the small GEMM, fp32 attention and
+    residual stream; every golden is that small) and, with `no_small`, the large-batch kernels."""
     g = Golden(name)
     m = build(g, precision=precision)
     x = g.images().to(DEV)
-    with torch.no_grad():
+    with torch.no_grad(), _lib.option("no_small", int(route == "large")):
         mask, logits = m.predict_mask(x, return_logits=True)
     torch.cuda.synchronize()
     err, _ = g.max_abs_err("logits", logits)

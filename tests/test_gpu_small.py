@@ -144,6 +144,43 @@ def test_wgrad_small_both_operands_token_major(M, Nd, Kd):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("f16", [0, 1])
+@pytest.mark.parametrize("M,N,K,epi", [(788, 2304, 768, 0), (788, 3072, 768, 1), (788, 768, 768, 2), (788, 768, 3072, 2),
+                                       (197, 2304, 768, 0), (197, 3072, 768, 1), (197, 768, 3072, 2), (74, 576, 192, 0),
+                                       (1576, 1536, 512, 0), (3140, 3072, 1024, 1), (50, 1024, 1024, 2), (300, 192, 192, 2)])
+def test_linear_small_16bit_operands(M, N, K, epi, f16):
+    """The 16-bit form of the small-batch linears (the same kernels on v_mfma_f32_32x32x16_bf16 / _f16): bias -> fp32,
+    bias + GELU -> 16-bit (the next GEMM's operand), chunk slabs -> fp32 -- against fp64 on the SAME 16-bit operand values;
+    rows do not depend on M (every tile variant and the one-image kernel give the same bits)."""
+    dt = torch.float16 if f16 else torch.bfloat16
+    A = (_rand(M, K, seed=1) * 0.7).to(dt).to(DEV)
+    W = (_rand(N, K, seed=2) * 0.05).to(dt).to(DEV)
+    bias = _rand(N, seed=3).to(DEV)
+    ref = A.double() @ W.double().T + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+
+    def run(a, rows):
+        C = torch.full((rows, N), float("nan"), device=DEV, dtype=dt if epi == 1 else torch.float32)
+        S = _lib.lib().vitseg_small_splits(N, K)
+        scratch = torch.empty((S + 1) * rows * N, device=DEV) if epi == 2 else None
+        _lib.check(_lib.lib().vitseg_op_linear_h16_small(a.data_ptr(), W.data_ptr(), bias.data_ptr(), C.data_ptr(), rows, N, K, epi, f16,
+                                                         scratch.data_ptr() if epi == 2 else None, scratch.numel() if epi == 2 else 0,
+                                                         _stream()))
+        return C
+
+    outs = []
+    for v in range(0, 8):   # the planner's choice, then every tile variant and the one-image kernels (skipped where they do not apply)
+        with _lib.option("small_variant", v):
+            outs.append(run(A, M))
+    tol = 2e-5 * max(1.0, ref.abs().max().item()) if epi != 1 else (1e-3 if f16 else 8e-3) * max(1.0, ref.abs().max().item())
+    assert (outs[0].double() - ref).abs().max().item() < tol
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    few = run(A[:5].contiguous(), 5)
+    assert torch.equal(few, outs[0][:5])
+
+
 def _attention_ref(qkv, B, Np, A):
     """fp64 softmax(q k^T / 8) v on the patches-first row layout (patch token t of image b in row b Np + t, CLS in row B Np + b)."""
     D = 64 * A
@@ -329,13 +366,14 @@ def test_small_route_equals_large_route_within_rounding_and_oracle(P, D, L, A):
     assert int(((mask.cpu().long() != O.predict_mask(ref)) & stable).sum()) == 0 and float((~stable).float().mean()) < 2e-3
 
 
-def test_small_route_batch_invariance_vit_base():
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+def test_small_route_batch_invariance_vit_base(precision):
     """ViT-B/16 (2 layers) at 224x224: images 1..2 of a batch of 8 (1576 rows) = the same two images as a batch of 2, and image
-    0 = a batch of 1, bit for bit (logits and masks)."""
+    0 = a batch of 1, bit for bit (logits and masks) -- in fp32 and in the route's 16-bit forms."""
     cfg = ViTSegConfig(17, 16, 768, 2, 12, image_size=224)
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=3).items()}
     x = torch.from_numpy(synth.make_images(cfg, 8, seed=2)).to(DEV)
-    m = ViTSegmentationModel(17, 16, 768, 2, 12, image_size=224, device=DEV).eval()
+    m = ViTSegmentationModel(17, 16, 768, 2, 12, image_size=224, precision=precision, device=DEV).eval()
     m.load_state_dict(sd)
     with torch.no_grad():
         m8, l8 = m.predict_mask(x, return_logits=True)

@@ -29,7 +29,8 @@ __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 
 // probabilities are dropped AFTER the normalising sum is taken (torch: dropout(softmax(s))), with the mask of
 // attention_f32.hip -- key (seed, stream, (b A + head) N + query), element = key index.
 __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
-                                                            float* __restrict__ lse, int B, int Np, int A, DropArgs dr) {
+                                                            float* __restrict__ lse, int B, int Np, int A, DropArgs dr,
+                                                            int ctx_fmt) {
     __shared__ __attribute__((aligned(16))) float vt[4][32 * HD];        // per wave: V tile [key][d]
     __shared__ __attribute__((aligned(16))) float om[4][32 * HD];        // per wave: partial output [query][d]
     __shared__ float ml[4][2][32];                                       // per wave: running max / sum per query
@@ -183,19 +184,31 @@ __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restr
                 acc0[e] *= inv;
                 acc1[e] *= inv;
             }
-            float* dst = ctx + token_row(tok) * D + head * HD + d0;
-            *(f32x4*)dst = acc0;
-            *(f32x4*)(dst + 4) = acc1;
+            if (ctx_fmt == 0) {
+                float* dst = ctx + token_row(tok) * D + head * HD + d0;
+                *(f32x4*)dst = acc0;
+                *(f32x4*)(dst + 4) = acc1;
+            } else {   // the 16-bit route: ctx is o_proj's operand
+                uint4 h;
+                if (ctx_fmt == 2) {
+                    h.x = H16<f16_t>::pack2(acc0[0], acc0[1]); h.y = H16<f16_t>::pack2(acc0[2], acc0[3]);
+                    h.z = H16<f16_t>::pack2(acc1[0], acc1[1]); h.w = H16<f16_t>::pack2(acc1[2], acc1[3]);
+                } else {
+                    h.x = pack2_bf16(acc0[0], acc0[1]); h.y = pack2_bf16(acc0[2], acc0[3]);
+                    h.z = pack2_bf16(acc1[0], acc1[1]); h.w = pack2_bf16(acc1[2], acc1[3]);
+                }
+                *(uint4*)((unsigned short*)ctx + token_row(tok) * D + head * HD + d0) = h;
+            }
         }
     }
 }
 
 }  // namespace
 
-int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s, float* lse, DropArgs dr) {
+int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s, float* lse, DropArgs dr, int ctx_fmt) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_small: bad arguments");
     const int QT = (Np + 1 + 31) / 32;
-    hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)(B * A * QT)), dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr);
+    hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)(B * A * QT)), dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr, ctx_fmt);
     VITSEG_LAUNCH_CHECK("attention_small");
     return VITSEG_OK;
 }

@@ -20,6 +20,8 @@
 //     (finished) ring and written as whole 128-byte row pieces.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "small.hpp"
 
 namespace vitseg {
@@ -37,8 +39,14 @@ struct Variant {
 constexpr Variant VARIANTS[] = {{1, 2, 2, 2, 3}, {1, 1, 1, 4, 4}, {1, 3, 2, 2, 3}, {2, 2, 2, 2, 3}, {1, 1, 2, 2, 4}};
 constexpr int NVARIANTS = sizeof(VARIANTS) / sizeof(VARIANTS[0]);
 
-template <int V, int EPI, int AMODE>
+// H: 0 = fp32 operands (v_mfma_f32_32x32x2_f32); 1 / 2 = bf16 / fp16 operands (v_mfma_f32_32x32x16_*): the SAME bytes move --
+// the launcher hands K / lda / ldw in 4-byte units, a 128-byte row piece is 64 values, and the 16-byte chunk (2 j + lh) a lane
+// reads is exactly the eight values (k = 16 j + 8 lh ..) the wide MFMA takes from it -- so only the products and the store of
+// the GELU epilogue (the next GEMM's 16-bit operand) differ.  SA_PLAIN only.
+template <int V, int EPI, int AMODE, int H = 0>
 __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
+    static_assert(H == 0 || (AMODE == SA_PLAIN && (EPI == SE_PARTIAL || EPI == SE_BIAS || EPI == SE_GELU)), "16-bit operands: the forward linears");
+    typedef typename std::conditional<H == 2, f16_t, bf16_t>::type HT;
     constexpr Variant CV = VARIANTS[V];
     constexpr int MT = CV.MT, NT = CV.NT, WGN = CV.WGN, NSTAGE = CV.NSTAGE;
     constexpr int BM = CV.bm(), BN = CV.bn();
@@ -227,14 +235,22 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    auto mfma_group = [&](int slot) {   // chunk pair j: k = 8 j + 4 lh + e, e = 0..3
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
+    auto mfma_group = [&](int slot) {   // chunk pair j: k = 8 j + 4 lh + e, e = 0..3 (16-bit: k = 16 j + 8 lh + 0..7 in one product)
+        if constexpr (H != 0) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][nt][e], fa[slot][mt][e], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = H16<HT>::mfma(__builtin_bit_cast(bf16x8, fw[slot][nt]), __builtin_bit_cast(bf16x8, fa[slot][mt]), acc[mt][nt]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][nt][e], fa[slot][mt][e], acc[mt][nt], 0, 0, 0);
+        }
     };
 
     // Direct epilogues (one K chunk per launch) sum the reduction in p.kh equal pieces -- acc is folded into `sum` and
@@ -340,7 +356,11 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf_grad(u[e]);
                 }
-                if (live) *(f32x4*)(cbase + o) = v;
+                if (H != 0 && EPI == SE_GELU) {   // the MLP hidden as the next GEMM reads it: 16-bit
+                    if (live) *(uint2*)((unsigned short*)cbase + o) = uint2{H16<HT>::pack2(v[0], v[1]), H16<HT>::pack2(v[2], v[3])};
+                } else if (live) {
+                    *(f32x4*)(cbase + o) = v;
+                }
             }
         }
     if (stamp) {
@@ -358,8 +378,9 @@ __global__ __launch_bounds__(320) void gemm_f32s_kernel(const SGemm p) {
 // loader wave streams the four pieces side by side (a ring stage = 4 x (32 + 32 NT) operand rows); the pieces are parked in
 // LDS and added in piece order ((h0 + h1) + h2) + h3 -- exactly what gemm_f32s_kernel's FOLD computes one piece after the
 // other, so the two kernels give the same bits and small_plan may pick either by M.
-template <int NT, int EPI>
+template <int NT, int EPI, int H = 0>
 __global__ __launch_bounds__(320) void gemm_f32s_kw_kernel(const SGemm p) {
+    typedef typename std::conditional<H == 2, f16_t, bf16_t>::type HT;
     constexpr int BN = 32 * NT, CHROWS = 32 + BN;
     constexpr int STAGE = 4 * CHROWS * 128;
     constexpr int NSTAGE = 163840 / STAGE >= 3 ? 3 : 2;
@@ -445,11 +466,17 @@ __global__ __launch_bounds__(320) void gemm_f32s_kw_kernel(const SGemm p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
     auto mfma_group = [&](int slot) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
+        if constexpr (H != 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][nt][e], fa[slot][e], acc[nt], 0, 0, 0);
+                acc[nt] = H16<HT>::mfma(__builtin_bit_cast(bf16x8, fw[slot][nt]), __builtin_bit_cast(bf16x8, fa[slot]), acc[nt]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][nt][e], fa[slot][e], acc[nt], 0, 0, 0);
+        }
     };
     __builtin_amdgcn_s_barrier();   // B0
     __builtin_amdgcn_sched_barrier(0);
@@ -512,7 +539,11 @@ __global__ __launch_bounds__(320) void gemm_f32s_kw_kernel(const SGemm p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         }
-        if (live) *(f32x4*)(p.C + (size_t)grow * p.ldc + gcol) = v;
+        if (H != 0 && EPI == SE_GELU) {
+            if (live) *(uint2*)((unsigned short*)p.C + (size_t)grow * p.ldc + gcol) = uint2{H16<HT>::pack2(v[0], v[1]), H16<HT>::pack2(v[2], v[3])};
+        } else if (live) {
+            *(f32x4*)(p.C + (size_t)grow * p.ldc + gcol) = v;
+        }
     }
 }
 
@@ -534,7 +565,10 @@ int small_plan(const SGemm& a, int kc, int epi, int amode) {
         const int occ = 163840 / V.lds() < 1 ? 1 : 163840 / V.lds();
         // measured with in-kernel stamps (tools/small_stamps.py, profiles/r05_small_stamps_*.txt): a K step costs its MFMAs
         // (1024 cycles per tile) + ~200 for the barrier; prologue ~2700, epilogue ~1600 per tile, ~3000 of launch ramp
-        const double stream = (double)(kc / 32) * (V.MT * V.NT * 1024 + 200);
+        // (16-bit operands: 4 products of 32 cycles per tile and step -- the step is the loader's: ~25 cycles per 1 KiB piece)
+        const int pieces = (V.bm() + V.bn()) / 8;
+        const double step = a.h16 ? (V.MT * V.NT * 128 > 25 * pieces ? V.MT * V.NT * 128 : 25 * pieces) : V.MT * V.NT * 1024;
+        const double stream = (double)(kc / 32) * (step + 200);
         const double fixed = 5700.0 + 1600.0 * V.MT * V.NT;
         const double time = per_cu * stream + ((per_cu + occ - 1) / occ) * fixed;
         if (time < best) {
@@ -546,7 +580,8 @@ int small_plan(const SGemm& a, int kc, int epi, int amode) {
         if (!kw_applies(a, epi, amode, nt)) continue;
         const long blocks = (long)((a.M + 31) / 32) * (a.N / (32 * nt));
         const long per_cu = (blocks + ncu - 1) / ncu;
-        const double time = per_cu * ((double)(a.K / 128) * (nt * 1024 + 200) + 7200.0 + 1600.0 * nt);
+        const double kstep = a.h16 ? (nt * 128 > 25 * (4 + 4 * nt) * 4 ? nt * 128 : 25 * (4 + 4 * nt) * 4) : nt * 1024;
+        const double time = per_cu * ((double)(a.K / 128) * (kstep + 200) + 7200.0 + 1600.0 * nt);
         if (time < best) {
             best = time;
             bv = KW_FIRST + nt - 2;
@@ -555,24 +590,24 @@ int small_plan(const SGemm& a, int kc, int epi, int amode) {
     return bv;
 }
 
-template <int NT, int EPI>
+template <int NT, int EPI, int H = 0>
 int launch_kw(const SGemm& a, hipStream_t s) {
     int dev = 0;
     static bool attr_set[64] = {};
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32s_kw_kernel<NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32s_kw_kernel<NT, EPI, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_f32s_kw)");
         attr_set[dev] = true;
     }
     constexpr int STAGE = 4 * (32 + 32 * NT) * 128;
     constexpr int LDS = (163840 / STAGE >= 3 ? 3 : 2) * STAGE;
-    hipLaunchKernelGGL((gemm_f32s_kw_kernel<NT, EPI>), dim3(a.tiles_m * a.tiles_n), dim3(320), LDS, s, a);
+    hipLaunchKernelGGL((gemm_f32s_kw_kernel<NT, EPI, H>), dim3(a.tiles_m * a.tiles_n), dim3(320), LDS, s, a);
     VITSEG_LAUNCH_CHECK("gemm_f32s_kw");
     return VITSEG_OK;
 }
 
-template <int V, int EPI, int AMODE>
+template <int V, int EPI, int AMODE, int H = 0>
 int launch_one(const SGemm& a, hipStream_t s) {
     constexpr int LDS0 = VARIANTS[V].lds();
     const int LDS = LDS0 + (a.lds_pad > 0 && LDS0 + a.lds_pad <= 163840 ? a.lds_pad : 0);
@@ -580,25 +615,41 @@ int launch_one(const SGemm& a, hipStream_t s) {
     static bool attr_set[64] = {};
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32s_kernel<V, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32s_kernel<V, EPI, AMODE, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_f32s)");
         attr_set[dev] = true;
     }
     const int blocks = a.tiles_m * a.tiles_n * a.splits;
-    hipLaunchKernelGGL((gemm_f32s_kernel<V, EPI, AMODE>), dim3(blocks), dim3(320), LDS, s, a);
+    hipLaunchKernelGGL((gemm_f32s_kernel<V, EPI, AMODE, H>), dim3(blocks), dim3(320), LDS, s, a);
     VITSEG_LAUNCH_CHECK("gemm_f32s");
     return VITSEG_OK;
 }
 
-template <int EPI, int AMODE>
+template <int EPI, int AMODE, int H = 0>
 int launch_variant(const SGemm& a, hipStream_t s) {
     switch (a.variant) {
-        case 0: return launch_one<0, EPI, AMODE>(a, s);
-        case 1: return launch_one<1, EPI, AMODE>(a, s);
-        case 2: return launch_one<2, EPI, AMODE>(a, s);
-        case 3: return launch_one<3, EPI, AMODE>(a, s);
-        default: return launch_one<4, EPI, AMODE>(a, s);
+        case 0: return launch_one<0, EPI, AMODE, H>(a, s);
+        case 1: return launch_one<1, EPI, AMODE, H>(a, s);
+        case 2: return launch_one<2, EPI, AMODE, H>(a, s);
+        case 3: return launch_one<3, EPI, AMODE, H>(a, s);
+        default: return launch_one<4, EPI, AMODE, H>(a, s);
     }
+}
+// 16-bit operands (SGemm::h16 = 1 bf16, 2 fp16): the forward linears
+template <int H>
+int launch_h16(const SGemm& a, int epi, hipStream_t s) {
+    if (a.variant >= NVARIANTS) {
+        const int nt = a.variant - NVARIANTS + 2;
+        if (nt == 2) return epi == SE_GELU ? launch_kw<2, SE_GELU, H>(a, s) : launch_kw<2, SE_BIAS, H>(a, s);
+        return epi == SE_GELU ? launch_kw<3, SE_GELU, H>(a, s) : launch_kw<3, SE_BIAS, H>(a, s);
+    }
+    switch (epi) {
+        case SE_PARTIAL: return launch_variant<SE_PARTIAL, SA_PLAIN, H>(a, s);
+        case SE_BIAS: return launch_variant<SE_BIAS, SA_PLAIN, H>(a, s);
+        case SE_GELU: return launch_variant<SE_GELU, SA_PLAIN, H>(a, s);
+    }
+    set_error("gemm_f32s: epilogue %d with 16-bit operands", epi);
+    return VITSEG_EINVAL;
 }
 
 }  // namespace
@@ -609,6 +660,12 @@ int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s) {
                      "gemm_f32s: a direct epilogue takes one chunk and its operand (bias / saved pre-activation)");
     VITSEG_CHECK_ARG(amode != SA_PLAIN_WT || epi == SE_PARTIAL || epi == SE_DGELU, VITSEG_EINVAL, "gemm_f32s: the T-form serves the activation gradients");
     VITSEG_CHECK_ARG(amode != SA_TT || (epi == SE_PARTIAL && a.splits == 1), VITSEG_EINVAL, "gemm_f32s: the TT form writes one plain chunk");
+    if (a.h16) {   // 16-bit operands: K / lda / ldw arrive in values; the kernels count 4-byte units (the same bytes move)
+        VITSEG_CHECK_ARG(a.h16 <= 2 && amode == SA_PLAIN && (epi == SE_PARTIAL || epi == SE_BIAS || epi == SE_GELU) && !a.aux, VITSEG_EINVAL,
+                         "gemm_f32s: 16-bit operands serve the forward linears (plain operands; partial / bias / GELU epilogue)");
+        VITSEG_CHECK_ARG(a.K % 2 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0, VITSEG_ESHAPE, "gemm_f32s: 16-bit K / leading dimensions");
+        a.K /= 2; a.lda /= 2; a.ldw /= 2;
+    }
     const int kc = amode == SA_CONV3 ? a.K : amode == SA_CONV3_ALL ? 9 * a.K : a.K / a.splits;
     VITSEG_CHECK_ARG(kc % 32 == 0 && a.K % 32 == 0 && (amode == SA_CONV3 || amode == SA_CONV3_ALL || kc * a.splits == a.K), VITSEG_ESHAPE, "gemm_f32s: K chunk %d is not a multiple of 32", kc);
     VITSEG_CHECK_ARG(a.N % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.ldc % 4 == 0, VITSEG_ESHAPE, "gemm_f32s: N / leading dimensions must be multiples of 4");
@@ -624,11 +681,13 @@ int launch_gemm_f32s(SGemm a, int epi, int amode, hipStream_t s) {
         const int nt = a.variant - KW_FIRST + 2;
         a.tiles_m = (a.M + 31) / 32;
         a.tiles_n = a.N / (32 * nt);
+        if (a.h16) return a.h16 == 2 ? launch_h16<2>(a, epi, s) : launch_h16<1>(a, epi, s);
         if (nt == 2) return epi == SE_GELU ? launch_kw<2, SE_GELU>(a, s) : launch_kw<2, SE_BIAS>(a, s);
         return epi == SE_GELU ? launch_kw<3, SE_GELU>(a, s) : launch_kw<3, SE_BIAS>(a, s);
     }
     a.tiles_m = (a.M + VARIANTS[a.variant].bm() - 1) / VARIANTS[a.variant].bm();
     a.tiles_n = (a.N + VARIANTS[a.variant].bn() - 1) / VARIANTS[a.variant].bn();
+    if (a.h16) return a.h16 == 2 ? launch_h16<2>(a, epi, s) : launch_h16<1>(a, epi, s);
     if (amode == SA_CONV3) return launch_variant<SE_PARTIAL, SA_CONV3>(a, s);
     if (amode == SA_PATCH) return launch_variant<SE_PARTIAL, SA_PATCH>(a, s);
     if (amode == SA_CONV3_ALL) return launch_variant<SE_RELU, SA_CONV3_ALL>(a, s);

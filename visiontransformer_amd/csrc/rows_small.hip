@@ -103,7 +103,19 @@ __global__ __launch_bounds__(256) void resln_kernel(const SRows p) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * wv[i][e] + bv[i][e];
-            ((f32x4*)hr)[lane + 64 * i] = o;
+            if (p.h_fmt == 0) {
+                ((f32x4*)hr)[lane + 64 * i] = o;
+            } else {   // the 16-bit route: H is the next GEMM's operand
+                uint2 h;
+                if (p.h_fmt == 2) {
+                    h.x = H16<f16_t>::pack2(o[0], o[1]);
+                    h.y = H16<f16_t>::pack2(o[2], o[3]);
+                } else {
+                    h.x = pack2_bf16(o[0], o[1]);
+                    h.y = pack2_bf16(o[2], o[3]);
+                }
+                ((uint2*)((unsigned short*)p.H + (size_t)row * p.D))[lane + 64 * i] = h;
+            }
         }
     }
 }

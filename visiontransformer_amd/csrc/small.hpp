@@ -57,6 +57,8 @@ struct SGemm {
     // s_memtime at entry / after the prologue / after the K loop / at exit, HW_ID, XCC_ID
     unsigned long long* stamps;
     int lds_pad;                     // extra dynamic LDS bytes per block (experiments: forces fewer blocks per CU)
+    int h16;                         // 0: fp32 operands; 1 / 2: A and W hold bf16 / fp16 values (K, lda, ldw count VALUES; SA_PLAIN; partial /
+                                     // bias epilogues write fp32, the GELU epilogue writes the 16-bit format: the next GEMM's operand)
 };
 
 // chunks of a reduction of length K feeding N outputs per row (shape-only rule, see above)
@@ -92,6 +94,7 @@ struct SRows {
     float eps;
     const float* Xres;        // residual source when it is not X itself (the training forward keeps every block input); null: X
     DropArgs drop;            // training: x = residual + dropout(chunk sum + bias)  (hidden dropout, modeling_vit.py:276,283)
+    int h_fmt;                // H as 0 fp32, 1 bf16, 2 fp16 (the 16-bit route: the next GEMM's operand), [rows, D] of that type
 };
 int launch_resln(const SRows& a, hipStream_t s);
 // out[i] = slab 0 [i] + slab 1 [i] + ... (chunk order): the activation gradients that a LayerNorm / attention backward reads
@@ -104,8 +107,9 @@ int launch_headfin(const float* partial, size_t split_stride, const float* b0, c
 
 // softmax(q k^T / 8) v for short sequences: one block per 32 queries of one (image, head), the four waves split the keys
 // lse (optional): [B, A, Np + 1] log2-domain log-sum-exp per query, saved for the backward; dr: dropout of the probabilities
+// ctx_fmt: ctx as 0 fp32, 1 bf16, 2 fp16 values (the 16-bit route: o_proj's operand)
 int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s, float* lse = nullptr,
-                           DropArgs dr = DropArgs{0, 0, 0, 1.f});
+                           DropArgs dr = DropArgs{0, 0, 0, 1.f}, int ctx_fmt = 0);
 // its backward (attention_bwd_small.hip): dqkv = (dq | dk | dv) from dctx, the saved qkv / ctx / lse; ONE launch, the
 // blocks of the first half produce dk / dv (32 keys each, the four waves split the queries), those of the second dq
 // (32 queries each, the waves split the keys); delta = rowsum(dctx o ctx) is formed inside
@@ -119,6 +123,12 @@ int launch_layernorm_bwd_small(const float* x, const float* w, const float* g, s
                                const float* dres_in, float* dres_out, float* dw, float* db, float* scratch, int rows, int D,
                                float eps, hipStream_t s, float* br_out = nullptr, DropArgs br_drop = DropArgs{0, 0, 0, 1.f},
                                float* br_dbias = nullptr);
+// the sequence lengths attn_small_kernel takes in the forward of the route (by the SHAPE only: a row's bits must not depend on the
+// batch): every length but the whole-64-key-tile ones that fill 128-query blocks (512x512 at P = 16: 1025 tokens), which take
+// attention_f32's tail-free loop (tools/attn_small_probe.py, profiles/r05_attn_small_probe.txt)
+inline bool attn_small_infer(int Np) { return !(Np % 64 == 0 && Np + 1 > 400 && Np + 1 <= 2048); }
+// row limit of the route's 16-bit form (bf16 / fp16 operands in the four linears, everything else as in fp32): by measurement
+inline long small_max_rows_16(int N) { return N <= 400 ? 1600 : 1024; }
 // the sequence lengths the short-sequence attention kernels take in the TRAINING step (a function of the shape only)
 inline bool attn_small_train(int Np) { return Np + 1 <= 400; }
 

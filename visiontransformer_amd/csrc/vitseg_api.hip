@@ -91,7 +91,8 @@ Plan make_plan(const Shape& s, int B, int precision) {
     p.zero = take(256);                               // zero page (padding taps of the bf16 3x3 loader)
     p.x = take(p.Mt * s.D * 4);                       // fp32 residual stream
     p.h = take(p.Mt * s.D * 4);                       // LN output / attention context (fp32 sized)
-    p.qkv = take(p.Mt * 3 * s.D * act);               // q | k | v
+    const bool small_rows = precision != VITSEG_F32X3 && (long)p.Mt < small_max_rows() && !opt(OPT_NO_SMALL);
+    p.qkv = take(p.Mt * 3 * s.D * (small_rows ? 4 : act));   // q | k | v (fp32 on the small-batch route, also in its 16-bit form)
     p.u = take(p.Mt * (size_t)s.I * act);             // MLP hidden
     p.f = take(p.Mp * MID * 4);                       // seg_head.0 output (fp32)
     p.z = take((size_t)B * s.C * s.Np * 4);           // low-res logits
@@ -102,7 +103,7 @@ Plan make_plan(const Shape& s, int B, int precision) {
         const size_t need = (size_t)whole_split((int)p.Mt, nk[0], nk[1], 32) * p.Mt * nk[0];
         if (need > p.thin_floats) p.thin_floats = need;
     }
-    if (precision == VITSEG_F32 && (long)p.Mt < small_max_rows() && !opt(OPT_NO_SMALL)) {   // K-chunk slabs of the small-batch route (small.hpp)
+    if (small_rows) {   // K-chunk slabs of the small-batch route (small.hpp)
         const size_t need[4] = {(size_t)small_splits(s.D, s.D) * p.Mt * s.D, (size_t)small_splits(s.D, s.I) * p.Mt * s.D,
                                 (size_t)small_splits(s.D, s.Kp) * p.Mt * s.D, (size_t)9 * p.Mp * MID};
         for (size_t n : need)
@@ -116,9 +117,13 @@ Plan make_plan(const Shape& s, int B, int precision) {
 // ---- the small-batch fp32 forward (small.hpp): fewer than SMALL_MAX_ROWS token rows ------------------------------
 // 7 launches per layer: QKV GEMM (+bias) | attention | o_proj chunks | chunk sum + bias + residual + LayerNorm |
 // fc1 GEMM (+bias, GELU) | fc2 chunks | chunk sum + bias + residual + the next LayerNorm.
-int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, const Plan& p, const float* params, const float* x,
-                  int batch, float* logits, uint8_t* mask, char* ws, hipStream_t st) {
+// precision VITSEG_BF16 / VITSEG_F16: the four linears of every block multiply 16-bit operands (weights from the 16-bit arena,
+// LayerNorm output / attention context / MLP hidden written in that format by their producers) on the wide MFMA of the same
+// kernels; the residual stream, q | k | v, the attention arithmetic, the patch embedding and the head stay fp32.
+int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, const Plan& p, const float* params, const void* params_lp,
+                  int precision, const float* x, int batch, float* logits, uint8_t* mask, char* ws, hipStream_t st) {
     auto W = [&](int t, int layer = 0) { return params + tensor_offset(lay, t, layer); };
+    const int h16 = precision == VITSEG_BF16 ? 1 : precision == VITSEG_F16 ? 2 : 0;
     float* X = (float*)(ws + p.x);
     float* H = (float*)(ws + p.h);
     float* QKV = (float*)(ws + p.qkv);
@@ -131,14 +136,17 @@ int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, c
     auto linear = [&](const float* A, int M, int K, int lda, int wt, int bt, int layer, float* C, int N, int epi, int kind) {
         SGemm g{};
         g.A = A; g.W = W(wt, layer); g.bias = W(bt, layer); g.C = C;
+        if (h16) g.W = (const float*)((const unsigned short*)params_lp + tensor_offset(lay, wt, layer));   // (A is 16-bit too: its producer wrote it so)
+        g.h16 = h16;
         g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldc = N;
         g.splits = epi == SE_PARTIAL ? small_splits(N, K) : 1;
         g.split_stride = dstride;
         ProfScope ps(kind, 2.0 * M * N * K, st);
         return launch_gemm_f32s(g, epi, SA_PLAIN, st);
     };
-    auto rows = [&](int splits, const float* bias, const float* lnw, const float* lnb, int ln_rows, bool embed) {
+    auto rows = [&](int splits, const float* bias, const float* lnw, const float* lnb, int ln_rows, bool embed, int h_fmt) {
         SRows r{};
+        r.h_fmt = h_fmt;
         r.X = X; r.partial = part; r.split_stride = dstride; r.splits = splits; r.bias = bias;
         r.pos = W(VITSEG_T_POS); r.cls = W(VITSEG_T_CLS); r.lnw = lnw; r.lnb = lnb; r.H = H;
         r.rows = Mt; r.Mp = Mp; r.Np = s.Np; r.D = D; r.ln_rows = ln_rows; r.embed = embed ? 1 : 0;
@@ -160,7 +168,7 @@ int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, c
         }
         if ((rc = launch_cls_rows(W(VITSEG_T_CLS), W(VITSEG_T_POS), X, batch, s.Np, D, st))) return rc;
         ProfScope ps(VITSEG_K_LAYERNORM, (double)Mt * D * 8, st);
-        if ((rc = launch_layernorm(X, W(VITSEG_T_LN1_W, 0), W(VITSEG_T_LN1_B, 0), H, Mt, D, cfg->layer_norm_eps, 0, st))) return rc;
+        if ((rc = launch_layernorm(X, W(VITSEG_T_LN1_W, 0), W(VITSEG_T_LN1_B, 0), H, Mt, D, cfg->layer_norm_eps, h16, st))) return rc;
     } else {
         SGemm g{};
         g.A = x; g.W = W(VITSEG_T_PATCH_W); g.C = part;
@@ -171,7 +179,7 @@ int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, c
             ProfScope ps(VITSEG_K_GEMM_PATCH, 2.0 * g.M * g.N * g.K, st);
             if ((rc = launch_gemm_f32s(g, SE_PARTIAL, SA_PATCH, st))) return rc;
         }
-        if ((rc = rows(g.splits, W(VITSEG_T_PATCH_B), W(VITSEG_T_LN1_W, 0), W(VITSEG_T_LN1_B, 0), Mt, true))) return rc;
+        if ((rc = rows(g.splits, W(VITSEG_T_PATCH_B), W(VITSEG_T_LN1_W, 0), W(VITSEG_T_LN1_B, 0), Mt, true, h16))) return rc;
     }
     for (int l = 0; l < s.L; ++l) {
         if ((rc = linear(H, Mt, D, D, VITSEG_T_WQKV, VITSEG_T_BQKV, l, QKV, 3 * D, SE_BIAS, VITSEG_K_GEMM_BIAS))) return rc;
@@ -182,17 +190,18 @@ int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, c
             // key-split kernel (tools/attn_small_probe.py, profiles/r05_attn_small_probe.txt: 197 and 785 tokens 1.1-2.7x
             // faster at every batch; 1025 tokens faster only at batch 1; 3137 tokens 1.4x faster at batch 1, 1.06x at 2,
             // 0.92x at 4: the rows of such a forward end at batch 5)
-            rc = (s.Np % 64 == 0 && s.N > 400 && s.N <= 2048) ? launch_attention_f32(QKV, H, nullptr, batch, s.Np, s.A, DropArgs{}, st)
-                                                : launch_attention_small(QKV, H, batch, s.Np, s.A, st);
+            // (the 16-bit form of the route exists for the key-split kernel's lengths only: small_applies)
+            rc = attn_small_infer(s.Np) ? launch_attention_small(QKV, H, batch, s.Np, s.A, st, nullptr, DropArgs{0, 0, 0, 1.f}, h16)
+                                        : launch_attention_f32(QKV, H, nullptr, batch, s.Np, s.A, DropArgs{}, st);
             if (rc) return rc;
         }
         if ((rc = linear(H, Mt, D, D, VITSEG_T_WO, VITSEG_T_BO, l, part, D, SE_PARTIAL, VITSEG_K_GEMM_RESADD))) return rc;
-        if ((rc = rows(small_splits(D, D), W(VITSEG_T_BO, l), W(VITSEG_T_LN2_W, l), W(VITSEG_T_LN2_B, l), Mt, false))) return rc;
+        if ((rc = rows(small_splits(D, D), W(VITSEG_T_BO, l), W(VITSEG_T_LN2_W, l), W(VITSEG_T_LN2_B, l), Mt, false, h16))) return rc;
         if ((rc = linear(H, Mt, D, D, VITSEG_T_W1, VITSEG_T_B1, l, U, s.I, SE_GELU, VITSEG_K_GEMM_GELU))) return rc;
         if ((rc = linear(U, Mt, s.I, s.I, VITSEG_T_W2, VITSEG_T_B2, l, part, D, SE_PARTIAL, VITSEG_K_GEMM_RESADD))) return rc;
         const bool last = l + 1 == s.L;   // the final LayerNorm covers the patch rows only (CLS is dropped, classes.py:250)
         if ((rc = rows(small_splits(D, s.I), W(VITSEG_T_B2, l), last ? W(VITSEG_T_LNF_W) : W(VITSEG_T_LN1_W, l + 1),
-                       last ? W(VITSEG_T_LNF_B) : W(VITSEG_T_LN1_B, l + 1), last ? Mp : Mt, false)))
+                       last ? W(VITSEG_T_LNF_B) : W(VITSEG_T_LN1_B, l + 1), last ? Mp : Mt, false, last ? 0 : h16)))   // (the head reads fp32)
             return rc;
     }
     // ---- seg_head (a10 + a11): the 3x3 conv as nine shifted GEMMs (one tap per chunk), then ReLU + the 1x1 conv
@@ -229,9 +238,14 @@ long small_max_rows() {
 
 bool small_applies(const vitseg_config* cfg, int batch, int precision) {
     Shape s;
-    if (precision != VITSEG_F32 || opt(OPT_NO_SMALL) || check_config(cfg, &s)) return false;
+    if (precision == VITSEG_F32X3 || opt(OPT_NO_SMALL) || check_config(cfg, &s)) return false;
     const long rows = (long)batch * s.N;
-    return rows < small_max_rows() && s.D % 64 == 0 && s.I % 32 == 0 && s.I > s.D && s.S % 4 == 0;
+    if (!(rows < small_max_rows() && s.D % 64 == 0 && s.I % 32 == 0 && s.I > s.D && s.S % 4 == 0)) return false;
+    // 16-bit operands (inference): whole 64-value K steps per chunk, the sequence lengths of the key-split attention kernel (it
+    // writes the 16-bit context), and fewer rows than fp32 -- the route's attention stays fp32 arithmetic, the large-batch 16-bit
+    // kernels catch up at batch 8 of 197 tokens and at batch 2 of 785 (profiles/r05_h16_route_probe.txt)
+    if (precision != VITSEG_F32 && !(s.I % 64 == 0 && attn_small_infer(s.Np) && rows < small_max_rows_16(s.N))) return false;
+    return true;
 }
 }  // namespace vitseg
 
@@ -343,7 +357,7 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         return lp ? (const void*)((const unsigned short*)params_bf16 + off) : (const void*)(params + off);
     };
     char* ws = (char*)workspace;
-    if (small_applies(cfg, batch, precision)) return forward_small(cfg, s, lay, p, params, x, batch, logits, mask, ws, st);
+    if (small_applies(cfg, batch, precision)) return forward_small(cfg, s, lay, p, params, params_bf16, precision, x, batch, logits, mask, ws, st);
     float* X = (float*)(ws + p.x);
     void* H = (void*)(ws + p.h);      // fp32 or bf16 by precision
     void* QKV = (void*)(ws + p.qkv);
@@ -726,6 +740,36 @@ int vitseg_op_linear_f32_small(const float* A, const float* Wt, const float* bia
     g.A = A; g.W = Wt; g.bias = bias; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.splits = 1;
     return launch_gemm_f32s(g, epilogue == EPI_GELU ? SE_GELU : SE_BIAS, SA_PLAIN, (hipStream_t)stream);
+}
+
+// the 16-bit form of the route's linears (operands as raw bf16 / fp16 bits): epilogue 0 bias -> fp32 C, 1 bias + GELU -> 16-bit C,
+// 2 (chunked shapes) the K-chunk slabs into scratch, then C (fp32) = chunk sums in chunk order + bias
+int vitseg_op_linear_h16_small(const void* A, const void* Wt, const float* bias, void* C, int M, int N, int K, int epilogue, int f16,
+                               float* scratch, size_t scratch_floats, void* stream) {
+    VITSEG_CHECK_ARG(A && Wt && bias && C, VITSEG_EINVAL, "linear_h16_small: null pointer");
+    VITSEG_CHECK_ARG(epilogue >= 0 && epilogue <= 2, VITSEG_EINVAL, "linear_h16_small: epilogue %d", epilogue);
+    SGemm g{};
+    g.A = (const float*)A; g.W = (const float*)Wt; g.bias = bias; g.C = (float*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.splits = 1;
+    g.h16 = f16 ? 2 : 1;
+    if (epilogue != 2) {
+        VITSEG_CHECK_ARG(small_splits(N, K) == 1, VITSEG_ESHAPE, "linear_h16_small: N=%d K=%d is a chunked shape (epilogue 2)", N, K);
+        return launch_gemm_f32s(g, epilogue == 1 ? SE_GELU : SE_BIAS, SA_PLAIN, (hipStream_t)stream);
+    }
+    g.splits = small_splits(N, K);
+    g.split_stride = (size_t)M * N;
+    VITSEG_CHECK_ARG(scratch && scratch_floats >= (g.splits + 1) * g.split_stride, VITSEG_EWORKSPACE,
+                     "linear_h16_small: scratch %zu < %zu floats", scratch_floats, (g.splits + 1) * g.split_stride);
+    g.C = scratch;
+    if (int rc = launch_gemm_f32s(g, SE_PARTIAL, SA_PLAIN, (hipStream_t)stream)) return rc;
+    // chunk sums + bias through the rows kernel's own arithmetic: X = 0 + (sum + bias), its LayerNorm output discarded
+    float* zero = scratch + g.splits * g.split_stride;
+    hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(linear_h16_small)");
+    SRows r{};
+    r.X = (float*)C; r.partial = scratch; r.split_stride = g.split_stride; r.splits = g.splits; r.bias = bias;
+    r.lnw = bias; r.lnb = bias; r.H = zero; r.rows = M; r.Mp = M; r.Np = M; r.D = N; r.ln_rows = 0; r.embed = 0; r.eps = 1e-12f;
+    return launch_resln(r, (hipStream_t)stream);
 }
 
 int vitseg_op_linear_resln_f32_small(const float* A, const float* Wt, const float* bias, float* X, const float* lnw,
