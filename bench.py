@@ -642,6 +642,14 @@ def side_ref_grid(dev, reps=10):
                 e["ms_batch1"] = round(time_calls(lambda: model.predict_mask(x[:1], return_logits=True), reps, rounds=3) * 1e3, 3)
         if cid == 0:
             del model
+            # the route's 16-bit form (bf16 operands in the four linears of a block, fp32 everything else)
+            mb = ViTSegmentationModel(17, P, D, L, A, image_size=224, precision="bf16", device=dev).eval()
+            with torch.no_grad():
+                for xb, key in ((x, "ms_batch4_bf16"), (x[:1], "ms_batch1_bf16")):
+                    for _ in range(3):
+                        mb.predict_mask(xb, return_logits=True)
+                    e[key] = round(time_calls(lambda: mb.predict_mask(xb, return_logits=True), reps, rounds=3) * 1e3, 3)
+            del mb
             y4 = torch.from_numpy(synth.make_targets(cfg, 4, seed=0, size=224)).to(dev)
             mt = ViTSegmentationModel(17, P, D, L, A, image_size=224, device=dev, dropout=0.1)
             el, _, _ = run_train_steps(mt, x, y4, 1, 10, 3, 0, lambda: None)

@@ -91,7 +91,7 @@ Plan make_plan(const Shape& s, int B, int precision) {
     p.zero = take(256);                               // zero page (padding taps of the bf16 3x3 loader)
     p.x = take(p.Mt * s.D * 4);                       // fp32 residual stream
     p.h = take(p.Mt * s.D * 4);                       // LN output / attention context (fp32 sized)
-    const bool small_rows = precision != VITSEG_F32X3 && (long)p.Mt < small_max_rows() && !opt(OPT_NO_SMALL);
+    const bool small_rows = precision != VITSEG_F32X3 && (long)p.Mt < small_max_rows();   // (not the no_small switch: a workspace serves both routes)
     p.qkv = take(p.Mt * 3 * s.D * (small_rows ? 4 : act));   // q | k | v (fp32 on the small-batch route, also in its 16-bit form)
     p.u = take(p.Mt * (size_t)s.I * act);             // MLP hidden
     p.f = take(p.Mp * MID * 4);                       // seg_head.0 output (fp32)
