@@ -195,6 +195,10 @@ int vitseg_op_linear_h16_small(const void* A, const void* W, const float* bias, 
                                float* scratch, size_t scratch_floats, void* stream);
 /* attention core for short sequences (same arguments and layout as vitseg_op_attention_f32) */
 int vitseg_op_attention_f32_small(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream);
+/* its 16-bit form (what the route runs under VITSEG_BF16 / VITSEG_F16): fp32 q | k | v in; q, k, the probabilities and v rounded
+ * to bf16 (f16 = 0) or IEEE half in registers and multiplied on v_mfma_f32_32x32x16_*, fp32 accumulate and softmax; ctx16
+ * [Mt, D] written as 16-bit values (o_proj's operand) */
+int vitseg_op_attention_h16_small(const float* qkv, void* ctx16, int batch, int num_patches, int num_heads, int f16, void* stream);
 /* bf16 operands (A, W as raw bf16 bits), fp32 accumulate; bias and R fp32.  C is bf16 for epilogues 0/1
  * (tensors that feed the next MFMA) and fp32 for epilogue 2 (the residual stream). */
 int vitseg_op_linear_bf16(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N,

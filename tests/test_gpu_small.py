@@ -209,6 +209,28 @@ def test_attention_small(B, Np, A):
     assert (ctx - big).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("f16", [0, 1])
+@pytest.mark.parametrize("B,Np,A", [(1, 196, 12), (4, 196, 3), (2, 784, 2), (3, 16, 2), (2, 127, 1)])
+def test_attention_small_16bit_form(B, Np, A, f16):
+    """The key-split attention kernel with its products on the wide MFMA (q, k, P, v rounded to bf16 / fp16 in registers; fp32
+    softmax and accumulation), as the 16-bit form of the route runs it: against fp64 attention on the fp32 inputs within the
+    format's rounding, and batch-invariant bit for bit."""
+    rows, D = B * Np + B, 64 * A
+    qkv = _rand(rows, 3 * D, seed=B * 1000 + Np, scale=1.5).to(DEV)
+    dt = torch.float16 if f16 else torch.bfloat16
+    ctx = torch.full((rows, D), float("nan"), device=DEV, dtype=dt)
+    _lib.check(_lib.lib().vitseg_op_attention_h16_small(qkv.data_ptr(), ctx.data_ptr(), B, Np, A, f16, _stream()))
+    ref = _attention_ref(qkv.cpu(), B, Np, A)
+    err = (ctx.double().cpu() - ref).abs().max().item()
+    # |v| reaches ~6 here and the softmax is peaked (scores of std ~2): an output is close to ONE rounded v row, i.e. the budget
+    # is a few units of the format's spacing at 6 (bf16: 2^-6 ... 2^-5 = 0.03; fp16: 2^-9 ... 2^-8 = 0.004) plus P's rounding
+    assert err < (8e-3 if f16 else 6e-2), err
+    one = torch.cat([qkv[(B - 1) * Np:B * Np], qkv[B * Np + B - 1:B * Np + B]]).contiguous()   # the last image alone
+    c1 = torch.empty((Np + 1, D), device=DEV, dtype=dt)
+    _lib.check(_lib.lib().vitseg_op_attention_h16_small(one.data_ptr(), c1.data_ptr(), 1, Np, A, f16, _stream()))
+    assert torch.equal(c1[:Np], ctx[(B - 1) * Np:B * Np]) and torch.equal(c1[Np], ctx[B * Np + B - 1])
+
+
 def test_attention_small_is_batch_invariant():
     """Image 1 of a batch of 4 = that image alone (its rows re-packed into the patches-first layout of a batch of 1)."""
     B, Np, A = 4, 196, 12

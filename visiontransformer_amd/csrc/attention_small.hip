@@ -15,6 +15,8 @@
 //     memory into the MFMA A operand (a lane reads 16-byte pieces of its key's row), V through a wave-private 8 KiB LDS
 //     tile for the transposed read; exact fp32 MFMAs (v_mfma_f32_32x32x2_f32).
 // head_dim is 64 in every configuration of the reference.  Bound: latency (0.5 GFLOP per layer at batch 4).
+#include <type_traits>
+
 #include "small.hpp"
 
 namespace vitseg {
@@ -28,6 +30,12 @@ __device__ __forceinline__ int kappa(int s, int h) { return (s & 3) + 8 * (s >> 
 // Training (lse != null and / or dr.thresh != 0): the log2-domain log-sum-exp of every query is saved for the backward and the
 // probabilities are dropped AFTER the normalising sum is taken (torch: dropout(softmax(s))), with the mask of
 // attention_f32.hip -- key (seed, stream, (b A + head) N + query), element = key index.
+// MM: 0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 1 / 2 = the 16-bit form of the route: q, k, the probabilities and v are
+// rounded to bf16 / fp16 in registers and multiplied on v_mfma_f32_32x32x16_* (4 + 4 products per key tile instead of 32 + 32;
+// fp32 accumulate, fp32 softmax).  The operand slots of the wide MFMA are filled from the SAME register / LDS layout as the
+// fp32 form -- slot e of half lh is head-dim element 8 (2 j + (e >> 2)) + 4 lh + (e & 3) on both sides of q k^T, and key
+// kappa(8 j + e, lh) on both sides of P V -- so nothing is re-laid out.
+template <int MM>
 __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                             float* __restrict__ lse, int B, int Np, int A, DropArgs dr,
                                                             int ctx_fmt) {
@@ -58,6 +66,17 @@ __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) qreg[4 * c + e] = t[e] * (0.125f * LOG2E);
     }
 
+    typedef typename std::conditional<MM == 2, f16_t, bf16_t>::type HT;
+    auto pack8 = [](float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+        return __builtin_bit_cast(bf16x8, uint4{H16<HT>::pack2(a0, a1), H16<HT>::pack2(a2, a3), H16<HT>::pack2(a4, a5), H16<HT>::pack2(a6, a7)});
+    };
+    bf16x8 qh[4];
+    if constexpr (MM != 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            qh[j] = pack8(qreg[8 * j], qreg[8 * j + 1], qreg[8 * j + 2], qreg[8 * j + 3], qreg[8 * j + 4], qreg[8 * j + 5], qreg[8 * j + 6],
+                          qreg[8 * j + 7]);
+    }
     const unsigned dkey = drop_key(dr.seed, dr.stream, (unsigned)((b * A + head) * N + q_tok));
     const int KTn = (N + 31) / 32;
     f32x4 kreg[8], vreg[8];
@@ -89,10 +108,17 @@ __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restr
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        if constexpr (MM != 0) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+            for (int j = 0; j < 4; ++j)
+                sacc = H16<HT>::mfma(pack8(kreg[2 * j][0], kreg[2 * j][1], kreg[2 * j][2], kreg[2 * j][3], kreg[2 * j + 1][0], kreg[2 * j + 1][1],
+                                           kreg[2 * j + 1][2], kreg[2 * j + 1][3]), qh[j], sacc);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[c][e], qreg[4 * c + e], sacc, 0, 0, 0);
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[c][e], qreg[4 * c + e], sacc, 0, 0, 0);
+        }
         if (kt + 4 < KTn) load_tile(kt + 4);   // next tile's K / V in flight under the softmax and the PV products
         if (kt * 32 + 32 > N) {
 #pragma unroll
@@ -125,11 +151,26 @@ __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         // O^T += V^T P^T: A operand = V[key kappa(r, lh)][d = 32 dt + li] from LDS, B operand = the P registers
+        if constexpr (MM != 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v0 = vw[kappa(r, lh) * HD + li], v1 = vw[kappa(r, lh) * HD + 32 + li];
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[r], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sacc[r], o[1], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 pb = pack8(sacc[8 * j], sacc[8 * j + 1], sacc[8 * j + 2], sacc[8 * j + 3], sacc[8 * j + 4], sacc[8 * j + 5],
+                                        sacc[8 * j + 6], sacc[8 * j + 7]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    float t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = vw[kappa(8 * j + e, lh) * HD + 32 * dt + li];
+                    o[dt] = H16<HT>::mfma(pack8(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]), pb, o[dt]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v0 = vw[kappa(r, lh) * HD + li], v1 = vw[kappa(r, lh) * HD + 32 + li];
+                o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[r], o[0], 0, 0, 0);
+                o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sacc[r], o[1], 0, 0, 0);
+            }
         }
     }
 
@@ -208,7 +249,12 @@ __global__ __launch_bounds__(256, 2) void attn_small_kernel(const float* __restr
 int launch_attention_small(const float* qkv, float* ctx, int B, int Np, int A, hipStream_t s, float* lse, DropArgs dr, int ctx_fmt) {
     VITSEG_CHECK_ARG(qkv && ctx && B > 0 && Np > 0 && A > 0, VITSEG_EINVAL, "attention_small: bad arguments");
     const int QT = (Np + 1 + 31) / 32;
-    hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)(B * A * QT)), dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr, ctx_fmt);
+    // (the 16-bit form multiplies in its format; the training forward -- lse / dropout -- is fp32)
+    const int mm = ctx_fmt != 0 && !lse && !dr.thresh ? ctx_fmt : 0;
+    const dim3 grid((unsigned)(B * A * QT));
+    if (mm == 1) hipLaunchKernelGGL(attn_small_kernel<1>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr, ctx_fmt);
+    else if (mm == 2) hipLaunchKernelGGL(attn_small_kernel<2>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr, ctx_fmt);
+    else hipLaunchKernelGGL(attn_small_kernel<0>, grid, dim3(256), 0, s, qkv, ctx, lse, B, Np, A, dr, ctx_fmt);
     VITSEG_LAUNCH_CHECK("attention_small");
     return VITSEG_OK;
 }

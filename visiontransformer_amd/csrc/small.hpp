@@ -128,7 +128,7 @@ int launch_layernorm_bwd_small(const float* x, const float* w, const float* g, s
 // attention_f32's tail-free loop (tools/attn_small_probe.py, profiles/r05_attn_small_probe.txt)
 inline bool attn_small_infer(int Np) { return !(Np % 64 == 0 && Np + 1 > 400 && Np + 1 <= 2048); }
 // row limit of the route's 16-bit form (bf16 / fp16 operands in the four linears, everything else as in fp32): by measurement
-inline long small_max_rows_16(int N) { return N <= 400 ? 1600 : 1024; }
+inline long small_max_rows_16(int N) { return N <= 400 ? 3200 : 2400; }   // profiles/r05_h16_route_probe.txt: 197 tokens even at batch 16, 785 at batch 4
 // the sequence lengths the short-sequence attention kernels take in the TRAINING step (a function of the shape only)
 inline bool attn_small_train(int Np) { return Np + 1 <= 400; }
 

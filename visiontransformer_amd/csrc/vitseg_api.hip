@@ -119,7 +119,8 @@ Plan make_plan(const Shape& s, int B, int precision) {
 // fc1 GEMM (+bias, GELU) | fc2 chunks | chunk sum + bias + residual + the next LayerNorm.
 // precision VITSEG_BF16 / VITSEG_F16: the four linears of every block multiply 16-bit operands (weights from the 16-bit arena,
 // LayerNorm output / attention context / MLP hidden written in that format by their producers) on the wide MFMA of the same
-// kernels; the residual stream, q | k | v, the attention arithmetic, the patch embedding and the head stay fp32.
+// kernels, the attention products too (q, k, P, v rounded in registers, fp32 softmax); the residual stream, q | k | v as stored,
+// the patch embedding and the head stay fp32.
 int forward_small(const vitseg_config* cfg, const Shape& s, const Layout& lay, const Plan& p, const float* params, const void* params_lp,
                   int precision, const float* x, int batch, float* logits, uint8_t* mask, char* ws, hipStream_t st) {
     auto W = [&](int t, int layer = 0) { return params + tensor_offset(lay, t, layer); };
@@ -242,9 +243,10 @@ bool small_applies(const vitseg_config* cfg, int batch, int precision) {
     const long rows = (long)batch * s.N;
     if (!(rows < small_max_rows() && s.D % 64 == 0 && s.I % 32 == 0 && s.I > s.D && s.S % 4 == 0)) return false;
     // 16-bit operands (inference): whole 64-value K steps per chunk, the sequence lengths of the key-split attention kernel (it
-    // writes the 16-bit context), and fewer rows than fp32 -- the route's attention stays fp32 arithmetic, the large-batch 16-bit
-    // kernels catch up at batch 8 of 197 tokens and at batch 2 of 785 (profiles/r05_h16_route_probe.txt)
-    if (precision != VITSEG_F32 && !(s.I % 64 == 0 && attn_small_infer(s.Np) && rows < small_max_rows_16(s.N))) return false;
+    // writes the 16-bit context), and fewer rows than fp32 -- the large-batch 16-bit kernels (256 x 256 tiles) catch up at
+    // batch 16 of 197 tokens and at batch 4 of 785 (profiles/r05_h16_route_probe.txt)
+    const long lim16 = opt(OPT_SMALL_MAX_ROWS) > 0 ? opt(OPT_SMALL_MAX_ROWS) : small_max_rows_16(s.N);   // (the option: probes of the limit)
+    if (precision != VITSEG_F32 && !(s.I % 64 == 0 && attn_small_infer(s.Np) && rows < lim16)) return false;
     return true;
 }
 }  // namespace vitseg
@@ -819,6 +821,13 @@ int vitseg_op_wgrad_f32_small(const float* dY, const float* X, float* dW, int M,
 
 int vitseg_op_attention_f32_small(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
     return launch_attention_small(qkv, ctx, batch, num_patches, num_heads, (hipStream_t)stream);
+}
+// its 16-bit form (the small-batch route under VITSEG_BF16 / VITSEG_F16): fp32 q | k | v in, operands rounded in registers,
+// products on the wide MFMA, fp32 softmax, context written as 16-bit values
+int vitseg_op_attention_h16_small(const float* qkv, void* ctx16, int batch, int num_patches, int num_heads, int f16, void* stream) {
+    VITSEG_CHECK_ARG(qkv && ctx16, VITSEG_EINVAL, "attention_h16_small: null pointer");
+    return launch_attention_small(qkv, (float*)ctx16, batch, num_patches, num_heads, (hipStream_t)stream, nullptr,
+                                  DropArgs{0, 0, 0, 1.f}, f16 ? 2 : 1);
 }
 
 int vitseg_op_attention_f32(const float* qkv, float* ctx, int batch, int num_patches, int num_heads, void* stream) {
