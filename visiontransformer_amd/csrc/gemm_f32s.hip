@@ -2,7 +2,8 @@
 // the q/k/v/o projections, the MLP, the patch embedding and the 3x3 head conv of ViTSegmentationModel.forward
 // (/root/reference/model/CE/classes.py:246-257, transformers/models/vit/modeling_vit.py:62-69,207-254) at the batch
 // sizes the reference runs (4 x 224x224) and serves (1 image).  Exact fp32 products (v_mfma_f32_32x32x2_f32).
-// Roofline: fp32 matrix pipe, 157.3 TFLOP/s; algorithmic work 2 M N K per launch.
+// Roofline: fp32 matrix pipe, 157.3 TFLOP/s; algorithmic work 2 M N K per launch.  (16-bit operand form, template parameter H:
+// the same byte streams on v_mfma_f32_32x32x16_bf16 / _f16 -- bound by the loader wave's DMA issue rate, not the matrix pipe.)
 //
 // Why a third fp32 kernel: at 197-1576 rows the persistent 256x128 kernel (gemm_f32p.hip) has 1-7 row tiles and the
 // 128x128 tile kernel cut into K slices (whole_split) ran 6 slices of FOUR K steps each behind a 2 us prologue

@@ -8,6 +8,10 @@
 // published configuration (12 548 rows: 0.74 of the fp32 peak against 0.72) and loses to the persistent kernel at the
 // headline's 32 800 rows (0.85).
 //
+// The route has a 16-bit form (VITSEG_BF16 / VITSEG_F16 inference below small_max_rows_16 token rows): the SAME kernels with the
+// four linears of a block and the attention products on v_mfma_f32_32x32x16_* (SGemm::h16, SRows::h_fmt, attn_small_kernel<1|2>),
+// the residual stream, the stored q | k | v, the patch embedding and the head as in fp32.
+//
 // Summation order (what makes the results independent of the batch size inside the regime): a linear layer's reduction is
 // cut into small_splits(N, K) chunks -- a function of the layer's shape only, never of M -- each chunk is one fp32 fmaf
 // chain in the k order of gemm.hip's kernels (k = 32 kt + 8 j + 4 h + e), and the chunk sums are added in chunk order,
