@@ -714,6 +714,19 @@ def side_serve(dev, seconds=6.0):
             lat.append(time.perf_counter() - ta)
         mask0, counts0 = request(0, 1)
         torch.cuda.synchronize()
+        # the same single-image request with the forward in the small-batch route's 16-bit form (informational: the parity below
+        # and every figure above are the fp32 path)
+        mb = ViTSegmentationModel(C, 16, 768, 12, 12, image_size=S, precision="bf16", device=dev).eval()
+        mb.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        lat16 = []
+        for k in range(60):
+            ta = time.perf_counter()
+            mk16 = mb.predict_mask(pre.images(photos[k % NB:k % NB + 1]))
+            ev.counts(mk16, gt[k % NB:k % NB + 1])
+            torch.cuda.synchronize()
+            if k >= 10:
+                lat16.append(time.perf_counter() - ta)
+        del mb
     # one request against the oracle: the reference's own host pipeline on the same photo
     from PIL import Image
     im = Image.fromarray(host[0], "RGB").resize((S, S), Image.BILINEAR)
@@ -731,6 +744,7 @@ def side_serve(dev, seconds=6.0):
            "images_per_s_batch8": round(thr, 1), "requests_timed": len(lat),
            "latency_ms_single_image": {"p50": round(float(np.percentile(lat_ms, 50)), 3), "p99": round(float(np.percentile(lat_ms, 99)), 3),
                                        "min": round(float(lat_ms[0]), 3)},
+           "latency_ms_single_image_bf16_forward": {"p50": round(float(np.percentile(np.asarray(lat16) * 1e3, 50)), 3)},
            "parity_vs_oracle_one_request": {"input_bit_exact_vs_pillow": bool(torch.equal(x_dev.cpu(), xr)),
                                             "logits_max_abs_err": err, "mask_mismatch_at_stable_pixels": int((differ & stable).sum()),
                                             "unstable_pixels": int((~stable).sum())}}
