@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The reference's TRAINING regime (batch 4 x 224x224, model/CE/trainCurrentViTmodel.py:57): steps of ViT-B/16, 17 classes, for
-rocprofv3 --kernel-trace --stats.  python tools/train_small_probe.py [fp32|bf16] [steps]"""
+rocprofv3 --kernel-trace --stats.  python tools/train_small_probe.py [fp32|bf16] [steps] [batch]   (VITSEG_NO_SMALL=1: the large-batch kernels)"""
 import os
 import sys
 
@@ -14,12 +14,13 @@ from visiontransformer_amd.optim import FusedAdam  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = "cuda:0"
 cfg = ViTSegConfig(17, 16, 768, 12, 12, image_size=224)
 m = ViTSegmentationModel(17, 16, 768, 12, 12, image_size=224, precision=prec, dropout=0.1, device=dev).train()
 m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=1).items()})
-x = torch.from_numpy(synth.make_images(cfg, 4, seed=0)).to(dev)
-y = torch.from_numpy(synth.make_targets(cfg, 4, seed=0, size=224)).to(dev)
+x = torch.from_numpy(synth.make_images(cfg, B, seed=0)).to(dev)
+y = torch.from_numpy(synth.make_targets(cfg, B, seed=0, size=224)).to(dev)
 opt = FusedAdam(m.parameters(), lr=1e-5)
 def step():
     opt.zero_grad(set_to_none=True)
@@ -38,4 +39,4 @@ for _ in range(steps):
     loss = step()
 t1.record()
 torch.cuda.synchronize()
-print("loss", float(loss), "ms/step %.3f" % (t0.elapsed_time(t1) / steps))
+print("batch", B, "loss", float(loss), "ms/step %.3f" % (t0.elapsed_time(t1) / steps))
