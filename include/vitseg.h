@@ -110,7 +110,7 @@ const char* vitseg_last_error(void);
 /* Dispatcher switches for A/B measurements and tests (which kernel family takes a GEMM, precomputed dropout words on or
  * off, ...): process-wide, read by the launch path with one atomic load.  Names (case-insensitive): no_f32p, no_p8,
  * no_h16p, no_ragged_p8, no_dropmask, dropw_limit_mb, upsample_global, bf16_tiles, f32p_noinl, gn, no_mask2, no_small,
- * small_variant, small_max_rows.  Each starts from the environment variable VITSEG_<NAME> as it was when the library was loaded (the launch
+ * small_variant, small_max_rows, conv_dma.  Each starts from the environment variable VITSEG_<NAME> as it was when the library was loaded (the launch
  * path itself never calls getenv): a numeric value is taken as is (VITSEG_NO_P8=0 leaves the switch off), an empty or
  * non-numeric value of an on/off switch means 1.
  * The reference has no counterpart: its dispatch is ATen's. */

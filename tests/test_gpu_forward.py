@@ -417,6 +417,24 @@ def test_seventeen_classes_at_the_headline_size():
     assert torch.equal(O.predict_mask(up).to(torch.uint8), mask_all[7:8].cpu())
 
 
+def test_large_batch_head_conv_through_the_dma_kernel_is_bit_identical():
+    """The 3x3 head conv of a large-batch fp32 forward can run on gemm_f32s (switch conv_dma; SA_CONV3_ALL: operands through the
+    LDS-DMA ring, taps outside the image as out-of-range offsets) with the implicit GEMM's own fmaf chain per output: the same
+    bits as gemm.hip's kernel, here at 17 x 512x512 = 17 408 patch rows (above the small-batch route's limit), 2 layers."""
+    cfg = ViTSegConfig(2, 16, 768, 2, 12, image_size=512)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=5).items()}
+    x = torch.from_numpy(synth.make_images(cfg, 17, seed=4)).to(DEV)
+    m = ViTSegmentationModel(2, 16, 768, 2, 12, image_size=512, device=DEV).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        mk_a, lg_a = m.predict_mask(x, return_logits=True)
+        lg_a, mk_a = lg_a.clone(), mk_a.clone()
+        with _lib.option("conv_dma", 1):
+            mk_b, lg_b = m.predict_mask(x, return_logits=True)
+    assert torch.equal(lg_a, lg_b) and torch.equal(mk_a, mk_b)
+    assert torch.isfinite(lg_a).all() and float(lg_a.abs().max()) > 0
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_graph_replay_equals_eager(precision):
     """predict_mask_graphed: the forward captured as a hipGraph gives the same bits as the eager launch sequence, for

@@ -36,6 +36,7 @@ enum Opt {
     OPT_NO_SMALL,          // fp32 forwards of fewer than 2048 token rows on the large-batch kernels instead of the small-batch route (small.hpp)
     OPT_SMALL_VARIANT,     // gemm_f32s tile variant 1..5 for every launch (0: small_plan picks)
     OPT_SMALL_MAX_ROWS,    // fp32 forwards below this many token rows take the small-batch route (0: the built-in SMALL_MAX_ROWS)
+    OPT_CONV_DMA,          // the large-batch fp32 3x3 head conv on the LDS-DMA kernel (gemm_f32s SA_CONV3_ALL: same bits, -10 % time, 1.8x the L2-miss bytes) instead of gemm.hip's implicit GEMM
     OPT_COUNT
 };
 long opt(int id);

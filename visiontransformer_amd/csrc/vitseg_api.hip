@@ -35,7 +35,7 @@ int hip_fail(hipError_t e, const char* what) {
 // ---- dispatcher switches (common.hpp Opt) ----
 static const char* const g_opt_names[OPT_COUNT] = {"no_f32p", "no_p8", "no_h16p", "no_ragged_p8", "no_dropmask",
                                                    "dropw_limit_mb", "upsample_global", "bf16_tiles", "f32p_noinl", "gn", "no_mask2", "no_small",
-                                                   "small_variant", "small_max_rows"};
+                                                   "small_variant", "small_max_rows", "conv_dma"};
 static std::atomic<long> g_opts[OPT_COUNT];
 static int opt_index(const char* name) {
     if (!name) return -1;
@@ -442,7 +442,20 @@ int vitseg_forward(const vitseg_config* cfg, const float* params, const void* pa
         }
         {
             ProfScope ps(VITSEG_K_GEMM_CONV3, 2.0 * g.M * g.N * g.K, st);
-            rc = lp ? launch_gemm_bf16(g, A_CONV3, EPI_RELU, st, f16) : launch_gemm_f32(g, A_CONV3, EPI_RELU, st, x3);
+            if (!lp && !x3 && D % 32 == 0 && opt(OPT_CONV_DMA) && (size_t)(Mp + 128) * D * 4 < 0x7fffffffull) {
+                // (switch conv_dma, off by default) fp32: the same fmaf chain per output (k = (ky, kx, d): bit-identical to the
+                // implicit GEMM) with the operands through the LDS-DMA ring of gemm_f32s -- taps outside the image are out-of-range
+                // offsets that read as zeros.  Measured at the headline size (profiles/r05_notes.md): 0.94 -> 0.85 ms per forward,
+                // but 1 794 MB of L2 misses per launch against 978 MB: nine taps x two 128-column tiles re-read the map through
+                // the Infinity Cache.  Not the default: more traffic for 0.2 % of the step.
+                SGemm c{};
+                c.A = (const float*)H; c.W = W(VITSEG_T_HEAD0_W); c.bias = W(VITSEG_T_HEAD0_B); c.C = (float*)F;
+                c.M = Mp; c.N = MID; c.K = D; c.lda = D; c.ldw = 9 * D; c.ldc = MID; c.splits = 1;
+                c.g = s.g; c.Np = s.Np;
+                rc = launch_gemm_f32s(c, SE_RELU, SA_CONV3_ALL, st);
+            } else {
+                rc = lp ? launch_gemm_bf16(g, A_CONV3, EPI_RELU, st, f16) : launch_gemm_f32(g, A_CONV3, EPI_RELU, st, x3);
+            }
             if (rc) return rc;
         }
         ProfScope ps(VITSEG_K_HEAD1X1, (double)Mp * MID * 4 + (double)batch * s.C * s.Np * 4, st);
