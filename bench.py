@@ -412,7 +412,8 @@ def bench_ref_grid(args, rank, world, dev, barrier):
                  "images_per_s": round(B / t, 1), "vs_published": round(REF_PUBLISHED_S_PER_IMAGE[cid] / (t / B), 1),
                  "tflops": round(B * cfg.forward_flops_per_image() / t / 1e12, 2),
                  "frac_of_peak": round(B * cfg.forward_flops_per_image() / t / 1e12 / peak, 4),
-                 "launches_per_forward": model.graph_nodes(B, True), "graph_bit_identical": same}
+                 "launches_per_forward": model.graph_nodes(B, True), "graph_bit_identical": same,
+                 "route": model.forward_route(B)}
             if rank == 0 and not args.no_cpu_baseline and B == batches[0] and cpu_budget > 0:
                 t0 = time.perf_counter()
                 base, parity, _ = cpu_baseline(cfg, sd_np, images_np, logits, mask, seconds_budget=min(cpu_budget, 12.0),

@@ -130,6 +130,11 @@ int vitseg_cast_params_split(const float* params, void* params_split, size_t n_f
 /* same for IEEE half (VITSEG_F16); the shadow arena is passed in the params_bf16 slot of vitseg_forward */
 int vitseg_cast_params_f16(const float* params, void* params_f16, size_t n_floats, void* stream);
 
+/* Which kernels vitseg_forward takes for a call of this shape (host arithmetic, no GPU work): 1 = the small-batch route (fp32 below
+ * 16 384 token rows: the reference's batch 4 x 224x224 and the worker's single image; bf16 / fp16 below 3 200 rows at up to 400
+ * tokens, 2 400 at the other key-split lengths), 0 = the large-batch kernels; negative: a vitseg_status.  Results are bit-identical
+ * for every batch size INSIDE one route; the two routes sum in different orders (both within the parity gate). */
+int vitseg_forward_route(const vitseg_config* cfg, int batch, int precision);
 /* ---- forward (replaces ViTSegmentationModel.forward, classes.py:246-262, and the
  *      sigmoid->argmax post-processing of testViTModel.py:122-126) ---- */
 int vitseg_query_workspace(const vitseg_config* cfg, int batch, int precision, size_t* bytes);

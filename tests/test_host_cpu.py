@@ -170,3 +170,22 @@ def test_small_route_summation_rules_are_functions_of_the_shape():
     assert [f(768, 768), f(768, 3072), f(512, 512), f(512, 3072), f(1024, 1024), f(1024, 3072)] == [3, 6, 2, 6, 4, 6]
     assert [f(768, 2304), f(512, 1536), f(1024, 3072)] == [6, 3, 6]                               # dH1 = dQKV . Wqkv
     assert [f(192, 192), f(192, 3072), f(192, 576), f(768, 100)] == [1, 6, 3, 1]                   # Tiny/16; K % 32 != 0: one chunk
+
+
+def test_forward_route_is_host_arithmetic_on_the_shape():
+    """vitseg_forward_route (include/vitseg.h): which kernels a forward takes, decided from (configuration, batch, precision)
+    alone -- the reference's regime on the small-batch route, the headline on the large-batch kernels; no GPU needed."""
+    from visiontransformer_amd.config import vit_base16
+    b224 = ViTSegConfig(17, 16, 768, 12, 12, image_size=224)
+    r = _lib.forward_route
+    assert [r(b224, b, _lib.F32) for b in (1, 4, 64, 83, 84)] == ["small"] * 4 + ["large"]          # 197 tokens: < 16 384 rows
+    assert r(vit_base16(), 15, _lib.F32) == "small" and r(vit_base16(), 16, _lib.F32) == "large"      # 1025 tokens (512x512)
+    assert r(vit_base16(), 32, _lib.F32) == "large" and r(b224, 4, _lib.F32X3) == "large"
+    assert [r(b224, b, _lib.BF16) for b in (1, 4, 16, 17)] == ["small", "small", "small", "large"]     # 16-bit form: < 3 200 rows
+    assert r(vit_base16(), 1, _lib.BF16) == "large"                                                     # 1025 tokens: no 16-bit form
+    p8 = ViTSegConfig(17, 8, 768, 12, 12, image_size=224)
+    assert [r(p8, b, _lib.F16) for b in (1, 3, 4)] == ["small", "small", "large"]                      # 785 tokens: < 2 400 rows
+    with _lib.option("no_small", 1):
+        assert r(b224, 4, _lib.F32) == "large"
+    with pytest.raises(ValueError):
+        r(ViTSegConfig(2, 16, 100, 2, 2), 1, _lib.F32)

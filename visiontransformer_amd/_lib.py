@@ -35,7 +35,7 @@ EXPORTS = [
     "vitseg_op_gemm_f32", "vitseg_op_attention_bwd_f32", "vitseg_op_layernorm_bwd_f32", "vitseg_op_linear_h16_ex",
     "vitseg_op_wgrad_bf16", "vitseg_op_wgrad_bf16_scratch_floats", "vitseg_op_attention_bwd_bf16", "vitseg_attention_dropmask_bytes", "vitseg_attention_bwd_scratch_floats", "vitseg_op_colsum_scratch_floats",
     "vitseg_paed_binary_scratch_bytes", "vitseg_paed_binary_loss", "vitseg_op_linear_f32_ex", "vitseg_resize_nearest_i64",
-    "vitseg_small_splits", "vitseg_op_linear_f32_small", "vitseg_op_linear_resln_f32_small", "vitseg_op_attention_f32_small", "vitseg_op_attention_bwd_f32_small", "vitseg_op_linear_h16_small", "vitseg_op_attention_h16_small", "vitseg_op_layernorm_bwd_f32_small",
+    "vitseg_small_splits", "vitseg_op_linear_f32_small", "vitseg_op_linear_resln_f32_small", "vitseg_op_attention_f32_small", "vitseg_op_attention_bwd_f32_small", "vitseg_op_linear_h16_small", "vitseg_op_attention_h16_small", "vitseg_forward_route", "vitseg_op_layernorm_bwd_f32_small",
     "vitseg_dbg_linear_f32_small", "vitseg_adamw_step", "vitseg_op_dgrad_f32_small", "vitseg_op_wgrad_f32_small", "vitseg_op_layernorm_bwd_scratch_floats",
 ]
 VERSION = 110   # include/vitseg.h VITSEG_VERSION this binding was written against
@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
         l.vitseg_op_gemm_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         l.vitseg_op_attention_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
         l.vitseg_op_layernorm_bwd_f32_small.argtypes = [vp, vp, vp, sz, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, f32, C.c_uint32, C.c_uint32, vp]
+        l.vitseg_forward_route.argtypes = [pcfg, i32, i32]
         l.vitseg_op_attention_h16_small.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         l.vitseg_op_linear_h16_small.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]
         l.vitseg_op_attention_bwd_f32_small.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, C.c_uint32, C.c_uint32, vp]
@@ -209,6 +210,14 @@ def query_workspace(cfg: ViTSegConfig, batch: int, precision: int) -> int:
     n = C.c_size_t()
     check(lib().vitseg_query_workspace(C.byref(CConfig.from_config(cfg)), batch, precision, C.byref(n)))
     return n.value
+
+
+def forward_route(cfg: ViTSegConfig, batch: int, precision: int) -> str:
+    """"small" (the small-batch route of csrc/small.hpp) or "large": which kernels vitseg_forward takes for this call."""
+    rc = lib().vitseg_forward_route(C.byref(CConfig.from_config(cfg)), batch, precision)
+    if rc < 0:
+        check(rc)
+    return "small" if rc == 1 else "large"
 
 
 def workspace_offset(cfg: ViTSegConfig, batch: int, precision: int, buffer: int):

@@ -305,6 +305,14 @@ int vitseg_cast_params_f16(const float* params, void* params_f16, size_t n_float
     return launch_cast_bf16(params, params_f16, n_floats, (hipStream_t)stream, true);
 }
 
+// which kernels vitseg_forward takes for this call: 1 = the small-batch route (small.hpp), 0 = the large-batch kernels; < 0: error
+int vitseg_forward_route(const vitseg_config* cfg, int batch, int precision) {
+    Shape s;
+    if (int rc = check_config(cfg, &s)) return rc;
+    VITSEG_CHECK_ARG(batch >= 1 && precision >= VITSEG_F32 && precision <= VITSEG_F32X3, VITSEG_EINVAL, "forward_route: batch %d precision %d", batch, precision);
+    return small_applies(cfg, batch, precision) ? 1 : 0;
+}
+
 int vitseg_query_workspace(const vitseg_config* cfg, int batch, int precision, size_t* bytes) {
     Shape s;
     if (int rc = check_config(cfg, &s)) return rc;

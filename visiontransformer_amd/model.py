@@ -178,6 +178,11 @@ class ViTSegmentationModel(nn.Module):
                                f"same HIP device (input on {x.device}, parameters on {self.arena.device}). "
                                "There is no CPU fallback.")
 
+    def forward_route(self, batch: int) -> str:
+        """"small" / "large": the kernel family an inference forward of this batch size runs on (results are bit-identical for
+        every batch size inside one route)."""
+        return _lib.forward_route(self.cfg, batch, self.precision)
+
     def workspace(self, batch: int) -> torch.Tensor:
         key = (batch, self.precision)
         ws = self._ws.get(key)
