@@ -624,19 +624,35 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float b2, float eps, float step_size, float inv_bc2_sqrt,
                                                    float grad_scale, float decay) {
 #pragma clang fp contract(off)   // p.mul_(decay) is rounded before the update is subtracted, as torch does it
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+    // two 16-byte pieces of each stream per thread and trip (eight loads in flight); the gradient and the two moments are touched
+    // once per step: non-temporal, so that they do not push the parameters (re-read by the next forward) out of the caches
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+        f32x4 pv[2], gv[2], mv[2], vv[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float gr = gv[e] * grad_scale;
-            mv[e] = mv[e] + (gr - mv[e]) * (1.0f - b1);
-            vv[e] = vv[e] * b2 + (1.0f - b2) * gr * gr;
-            const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
-            pv[e] = pv[e] * decay - step_size * (mv[e] / denom);
+        for (int u = 0; u < 2; ++u) {
+            const size_t i = i0 + u * stride < n4 ? i0 + u * stride : i0;
+            pv[u] = ((f32x4*)p)[i];
+            gv[u] = __builtin_nontemporal_load((const f32x4*)g + i);
+            mv[u] = __builtin_nontemporal_load((f32x4*)m + i);
+            vv[u] = __builtin_nontemporal_load((f32x4*)v + i);
         }
-        ((f32x4*)p)[i] = pv;
-        ((f32x4*)m)[i] = mv;
-        ((f32x4*)v)[i] = vv;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t i = i0 + u * stride;
+            if (i >= n4) break;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gr = gv[u][e] * grad_scale;
+                mv[u][e] = mv[u][e] + (gr - mv[u][e]) * (1.0f - b1);
+                vv[u][e] = vv[u][e] * b2 + (1.0f - b2) * gr * gr;
+                const float denom = sqrtf(vv[u][e]) * inv_bc2_sqrt + eps;
+                pv[u][e] = pv[u][e] * decay - step_size * (mv[u][e] / denom);
+            }
+            ((f32x4*)p)[i] = pv[u];
+            __builtin_nontemporal_store(mv[u], (f32x4*)m + i);
+            __builtin_nontemporal_store(vv[u], (f32x4*)v + i);
+        }
     }
 }
 
