@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void resln_kernel(const SRows p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][e] += b4[e];
         }
-        if (p.drop.thresh) {   // the branch is dropped, not the residual (the mask of gemm.hip's EPI_RESADD: same key, same bits)
+        if (p.drop.thresh && !p.embed) {   // the branch is dropped, not the residual (the mask of gemm.hip's EPI_RESADD: same key, same bits)
             const unsigned key = drop_key(p.drop.seed, p.drop.stream, (unsigned)row);
 #pragma unroll
             for (int i = 0; i < NV; ++i)
@@ -70,10 +70,17 @@ __global__ __launch_bounds__(256) void resln_kernel(const SRows p) {
                     acc[i][e] = drop_keep(key, (unsigned)(4 * (lane + 64 * i) + e), p.drop.thresh) ? acc[i][e] * p.drop.scale : 0.f;
         }
     }
+    // embedding form in training: the SUM is dropped, CLS rows included (dropout(embeddings), modeling_vit.py:159; the mask of
+    // dropout_rows_kernel: key (seed, stream, row), element = column)
+    const bool drop_sum = p.embed && p.drop.thresh;
+    const unsigned ekey = drop_key(p.drop.seed, p.drop.stream, (unsigned)row);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] = res[i][e] + acc[i][e];
+        for (int e = 0; e < 4; ++e) {
+            v[i][e] = res[i][e] + acc[i][e];
+            if (drop_sum) v[i][e] = drop_keep(ekey, (unsigned)(4 * (lane + 64 * i) + e), p.drop.thresh) ? v[i][e] * p.drop.scale : 0.f;
+        }
         if (lane + 64 * i < nv) ((f32x4*)xr)[lane + 64 * i] = v[i];
     }
     if (row >= p.ln_rows) return;
